@@ -1,0 +1,123 @@
+/*
+ * poseidon252_hip.h — C ABI of libposeidon252_hip.so: batched Poseidon252 (Hades width-5 + SAFE
+ * sponge over the BLS12-381 scalar field) on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the reference's native hash path.  The reference
+ * (dusk-poseidon 0.42) has no FFI of its own; the seam this library replaces is
+ *     dusk_poseidon::Hash::{new, update, output_len, finalize, digest}   src/hash.rs:98-195
+ *     dusk_poseidon::Domain + From<Domain> for u64                        src/hash.rs:21-56
+ *     dusk_safe::Safe<BlsScalar, 5>::permute for ScalarPermutation        src/hades/permutation/scalar.rs:24-27
+ * A per-call replacement of Safe::permute would be one permutation per kernel launch, so the
+ * boundary is the BATCHED sibling of Hash with identical per-item semantics.  INTEGRATION.md shows
+ * the Rust `extern "C"` block and the `HashBatch` wrapper a maintainer would add.
+ *
+ * Scalars: every `uint64_t*` scalar buffer is an array of BlsScalar in the reference's memory
+ * layout — 4 little-endian u64 limbs of the Montgomery residue a*2^256 mod p, fully reduced — so a
+ * Rust `&[BlsScalar]` is passed as a pointer with zero conversion.  Outputs are fully reduced too
+ * (bit-exact equality with the reference is limb equality).
+ *
+ * Tag: the sponge capacity element state[0] = Safe::tag(...) = BlsScalar::hash_to_scalar(tag_input)
+ * (scalar.rs:29-31) is an explicit INPUT of every hashing call.  A Rust caller passes the value
+ * computed by the real dusk crates; p252_tag() is a host convenience whose byte-level recipe is
+ * not covered by any reference test ("parity unpinned").
+ *
+ * Errors: functions return 0 on success or a negative P252_ERR_*; nothing unwinds across the
+ * boundary.  Where the reference panics (Hash::finalize on an invalid io-pattern, hash.rs:124-137)
+ * this library returns P252_ERR_IO_PATTERN_VIOLATION / P252_ERR_INVALID_IO_PATTERN and the host
+ * wrapper raises.  There is NO CPU fallback: without a usable HIP device every compute entry point
+ * fails with P252_ERR_NO_DEVICE / P252_ERR_HIP.
+ *
+ * Threading: a context is bound to one device and used by one thread at a time; distinct contexts
+ * are independent.  Multi-GPU = one process (or thread) and one context per GPU; batches shard with
+ * no inter-GPU dependence.
+ */
+#ifndef POSEIDON252_HIP_H
+#define POSEIDON252_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P252_OK 0
+#define P252_ERR_IO_PATTERN_VIOLATION (-1) /* dusk_poseidon::Error::IOPatternViolation, src/error.rs:12-14 */
+#define P252_ERR_INVALID_IO_PATTERN (-2)   /* dusk_poseidon::Error::InvalidIOPattern,   src/error.rs:16-17 */
+#define P252_ERR_INVALID_ARGUMENT (-3)
+#define P252_ERR_HIP (-4)
+#define P252_ERR_NO_DEVICE (-5)
+
+/* Domain discriminants, in the declaration order of `enum Domain` (src/hash.rs:21-36) */
+#define P252_DOMAIN_MERKLE4 0
+#define P252_DOMAIN_MERKLE2 1
+#define P252_DOMAIN_ENCRYPTION 2
+#define P252_DOMAIN_OTHER 3
+
+#define P252_HADES_WIDTH 5 /* dusk_poseidon::HADES_WIDTH, src/lib.rs:17 */
+
+typedef struct p252_ctx p252_ctx;
+
+/* ---- lifecycle ---- */
+int p252_device_count(void);
+/* Binds to HIP device `device_id`, derives the constant tables from the embedded arc.bin / mds.bin
+ * (round_constants.rs:26-54, mds_matrix.rs:17-39) and uploads them. */
+int p252_create(int device_id, p252_ctx** out);
+void p252_destroy(p252_ctx* ctx);
+/* message for the last error on this context (ctx == NULL: last p252_create failure) */
+const char* p252_last_error(const p252_ctx* ctx);
+
+/* ---- batched compute, HOST buffers (synchronous; H2D + kernel + D2H) ---- */
+/* n independent Hades permutations: replaces Safe::permute / Hades::perm
+ * (scalar.rs:25-27, permutation.rs:105-123).  states/out: n x 5 scalars. */
+int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n);
+/* n independent sponge hashes with the same io-pattern: replaces Hash::finalize (hash.rs:128-155)
+ * for n messages of in_len scalars each (contiguous, message-major), out_len outputs each in
+ * squeeze order.  Merkle4 digest = (in_len 4, out_len 1).  in_len == 0 or out_len == 0 ->
+ * P252_ERR_INVALID_IO_PATTERN. */
+int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
+                    size_t out_len, uint64_t* out, size_t n);
+/* Arity-4 Merkle tree over Hash::digest(Domain::Merkle4, [c0,c1,c2,c3]) nodes; empty child slots
+ * are the zero scalar (hash.rs:22-26).  Levels are built until a single node remains.  `levels`
+ * (optional) receives every level above the leaves, bottom-up, p252_merkle4_levels_len(n_leaves)
+ * scalars.  n_leaves == 0 -> P252_ERR_INVALID_ARGUMENT. */
+int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                      uint64_t root[4], uint64_t* levels);
+size_t p252_merkle4_levels_len(size_t n_leaves);
+
+/* ---- batched compute, DEVICE buffers (asynchronous on `hip_stream`, a hipStream_t; NULL = the
+ * default stream).  Pointers are device addresses with the same layouts as above.  This is the
+ * path bench.py times: inputs already resident in HBM. ---- */
+int p252_permute_batch_device(p252_ctx* ctx, const void* d_states, void* d_out, size_t n, void* hip_stream);
+int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
+                           size_t out_len, void* d_out, size_t n, void* hip_stream);
+/* d_levels may be NULL (context-owned scratch is used); d_root receives 1 scalar. */
+int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
+                             void* d_root, void* d_levels, void* hip_stream);
+int p252_sync(p252_ctx* ctx, void* hip_stream);
+
+/* ---- constant-table exchange (multi-GPU: rank 0 broadcasts its derived table over RCCL, every
+ * rank imports it; byte-identical to what p252_create derives locally) ---- */
+size_t p252_tables_size(void);
+int p252_tables_export(p252_ctx* ctx, void* host_buf, size_t len);
+int p252_tables_import(p252_ctx* ctx, const void* host_buf, size_t len);
+
+/* ---- host helpers mirroring src/hash.rs ---- */
+/* From<Domain> for u64 (hash.rs:38-56) */
+int p252_domain_separator(int domain, uint64_t* sep_out);
+/* io_pattern() validation (hash.rs:62-85) + dusk-safe's pattern rules: 0, or
+ * P252_ERR_IO_PATTERN_VIOLATION (Merkle arity mismatch), P252_ERR_INVALID_IO_PATTERN (no absorb,
+ * zero-length call, out_len 0). */
+int p252_check_io_pattern(int domain, const size_t* absorb_lens, size_t n_absorbs, size_t out_len);
+/* UNPINNED convenience: tag = hash_to_scalar(tag_input(io_pattern, domain_sep)). */
+int p252_tag(int domain, const size_t* absorb_lens, size_t n_absorbs, size_t out_len, uint64_t tag_out[4]);
+/* finalize_truncated post-processing (hash.rs:164-183): canonical value & (2^250 - 1), as the raw
+ * limbs handed to JubJubScalar::from_raw.  Host-side, n scalars. */
+int p252_truncate250(const uint64_t* scalars, uint64_t* out_raw, size_t n);
+
+/* library/version introspection */
+const char* p252_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

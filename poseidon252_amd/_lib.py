@@ -1,0 +1,76 @@
+"""ctypes binding of libposeidon252_hip.so (include/poseidon252_hip.h).
+
+The extension is mandatory: a missing library raises ImportError-like RuntimeError at first use and
+a missing GPU makes Context() raise — there is no CPU path behind this package.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libposeidon252_hip.so")
+
+OK = 0
+ERR_IO_PATTERN_VIOLATION = -1
+ERR_INVALID_IO_PATTERN = -2
+ERR_INVALID_ARGUMENT = -3
+ERR_HIP = -4
+ERR_NO_DEVICE = -5
+
+# every symbol include/poseidon252_hip.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = (
+    "p252_device_count", "p252_create", "p252_destroy", "p252_last_error",
+    "p252_permute_batch", "p252_hash_batch", "p252_merkle4_tree", "p252_merkle4_levels_len",
+    "p252_permute_batch_device", "p252_hash_batch_device", "p252_merkle4_tree_device", "p252_sync",
+    "p252_tables_size", "p252_tables_export", "p252_tables_import",
+    "p252_domain_separator", "p252_check_io_pattern", "p252_tag", "p252_truncate250", "p252_version",
+)
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_szp = ctypes.POINTER(ctypes.c_size_t)
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_lib = None
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissing(
+            "%s not found: build it with `python -m poseidon252_amd.build` "
+            "(hipcc --offload-arch=gfx950).  poseidon252_amd has no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.p252_device_count.restype = ctypes.c_int
+    L.p252_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+    L.p252_destroy.argtypes = [_vp]
+    L.p252_destroy.restype = None
+    L.p252_last_error.argtypes = [_vp]
+    L.p252_last_error.restype = ctypes.c_char_p
+    L.p252_permute_batch.argtypes = [_vp, _u64p, _u64p, _sz]
+    L.p252_hash_batch.argtypes = [_vp, _u64p, _u64p, _sz, _sz, _u64p, _sz]
+    L.p252_merkle4_tree.argtypes = [_vp, _u64p, _u64p, _sz, _u64p, _u64p]
+    L.p252_merkle4_levels_len.argtypes = [_sz]
+    L.p252_merkle4_levels_len.restype = _sz
+    L.p252_permute_batch_device.argtypes = [_vp, _vp, _vp, _sz, _vp]
+    L.p252_hash_batch_device.argtypes = [_vp, _u64p, _vp, _sz, _sz, _vp, _sz, _vp]
+    L.p252_merkle4_tree_device.argtypes = [_vp, _u64p, _vp, _sz, _vp, _vp, _vp]
+    L.p252_sync.argtypes = [_vp, _vp]
+    L.p252_tables_size.restype = _sz
+    L.p252_tables_export.argtypes = [_vp, _vp, _sz]
+    L.p252_tables_import.argtypes = [_vp, _vp, _sz]
+    L.p252_domain_separator.argtypes = [ctypes.c_int, _u64p]
+    L.p252_check_io_pattern.argtypes = [ctypes.c_int, _szp, _sz, _sz]
+    L.p252_tag.argtypes = [ctypes.c_int, _szp, _sz, _sz, _u64p]
+    L.p252_truncate250.argtypes = [_u64p, _u64p, _sz]
+    L.p252_version.restype = ctypes.c_char_p
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int and name not in ("p252_device_count",):
+            pass
+    _lib = L
+    return L

@@ -1,0 +1,361 @@
+// api.cpp — C ABI of libposeidon252_hip.so (include/poseidon252_hip.h).
+// Host side only: context / device-memory management, io-pattern rules mirroring src/hash.rs,
+// launch sequencing.  All hashing runs in kernels.hip; there is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/poseidon252_hip.h"
+#include "blake2b.hpp"
+#include "kernels.h"
+#include "tables.hpp"
+#include "_gen/assets.inc"
+
+using namespace p252;
+
+struct p252_ctx {
+    int device = -1;
+    int32_t* d_tab = nullptr;
+    std::vector<int32_t> h_tab;
+    // grow-only scratch for the host-buffer entry points and the tree builder
+    void* d_in = nullptr;
+    size_t d_in_cap = 0;
+    void* d_out = nullptr;
+    size_t d_out_cap = 0;
+    void* d_lvl[2] = {nullptr, nullptr};
+    size_t d_lvl_cap[2] = {0, 0};
+    std::string err;
+};
+
+static std::string g_create_err;
+static std::mutex g_mu;
+
+static int fail(p252_ctx* ctx, int code, const std::string& msg) {
+    if (ctx)
+        ctx->err = msg;
+    else {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_create_err = msg;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, P252_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static int ensure(p252_ctx* ctx, void** buf, size_t* cap, size_t need) {
+    if (need <= *cap) return P252_OK;
+    if (*buf) HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(ctx, hipMalloc(buf, need));
+    *cap = need;
+    return P252_OK;
+}
+
+static const std::vector<int32_t>& host_tables() {
+    static const std::vector<int32_t> tab = [] {
+        HadesTables T;
+        derive_tables(ARC_BIN, MDS_BIN, T);
+        return encode_tables29(T);
+    }();
+    return tab;
+}
+
+static TagArg tag_arg(const uint64_t tag[4]) {
+    TagArg t;
+    std::memcpy(t.w, tag, 32);
+    return t;
+}
+
+extern "C" {
+
+const char* p252_version(void) { return "poseidon252_hip 0.1 (gfx950; 9x29-bit limbs; sparse partial rounds)"; }
+
+int p252_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int p252_create(int device_id, p252_ctx** out) {
+    if (!out) return fail(nullptr, P252_ERR_INVALID_ARGUMENT, "p252_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, P252_ERR_NO_DEVICE,
+                    std::string("no HIP device available (") + hipGetErrorString(e) +
+                        "); this library has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, P252_ERR_INVALID_ARGUMENT, "p252_create: bad device id");
+    p252_ctx* ctx = new p252_ctx();
+    ctx->device = device_id;
+    ctx->h_tab = host_tables();
+    hipError_t e2 = hipSetDevice(device_id);
+    if (e2 == hipSuccess) e2 = hipMalloc((void**)&ctx->d_tab, ctx->h_tab.size() * sizeof(int32_t));
+    if (e2 == hipSuccess)
+        e2 = hipMemcpy(ctx->d_tab, ctx->h_tab.data(), ctx->h_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) {
+        std::string msg = std::string("p252_create: ") + hipGetErrorString(e2);
+        delete ctx;
+        return fail(nullptr, P252_ERR_HIP, msg);
+    }
+    *out = ctx;
+    return P252_OK;
+}
+
+void p252_destroy(p252_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->d_in) (void)hipFree(ctx->d_in);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->d_lvl[i]) (void)hipFree(ctx->d_lvl[i]);
+    delete ctx;
+}
+
+const char* p252_last_error(const p252_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_create_err.c_str();
+}
+
+int p252_sync(p252_ctx* ctx, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device-buffer entry points
+// ------------------------------------------------------------------------------------------
+int p252_permute_batch_device(p252_ctx* ctx, const void* d_states, void* d_out, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!d_states || !d_out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "permute: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_permute(ctx->d_tab, d_states, d_out, n, (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
+                           size_t out_len, void* d_out, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    // dusk-safe rejects io-patterns with an empty absorb or squeeze -> Hash::finalize panics (hash.rs:134-137)
+    if (in_len == 0 || out_len == 0)
+        return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "hash: in_len and out_len must be > 0");
+    if (in_len > 0x7fffffffu || out_len > 0x7fffffffu)
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "hash: length too large");
+    if (n == 0) return P252_OK;
+    if (!tag || !d_in || !d_out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "hash: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (in_len == 4 && out_len == 1)
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, tag_arg(tag), d_in, 4 * n, d_out, n, st));
+    else
+        HIP_TRY(ctx, launch_sponge(ctx->d_tab, tag_arg(tag), d_in, (unsigned)in_len, (unsigned)out_len, d_out, n, st));
+    return P252_OK;
+}
+
+size_t p252_merkle4_levels_len(size_t n_leaves) {
+    size_t total = 0, c = n_leaves;
+    if (c == 0) return 0;
+    do {
+        c = (c + 3) / 4;
+        total += c;
+    } while (c > 1);
+    return total;
+}
+
+int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
+                             void* d_root, void* d_levels, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: n_leaves must be > 0");
+    if (!tag || !d_leaves || !d_root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const TagArg t = tag_arg(tag);
+    const char* cur = static_cast<const char*>(d_leaves);
+    size_t cur_n = n_leaves;
+    char* lv = static_cast<char*>(d_levels);
+    if (!d_levels) {  // ping-pong in context-owned scratch
+        const size_t l1 = (n_leaves + 3) / 4, l2 = (l1 + 3) / 4;
+        int rc = ensure(ctx, &ctx->d_lvl[0], &ctx->d_lvl_cap[0], l1 * 32);
+        if (rc) return rc;
+        rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], l2 * 32);
+        if (rc) return rc;
+    }
+    int parity = 0;
+    do {
+        const size_t next_n = (cur_n + 3) / 4;
+        char* next = d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]);
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st));
+        cur = next;
+        cur_n = next_n;
+        if (d_levels) lv += next_n * 32;
+        parity ^= 1;
+    } while (cur_n > 1);
+    HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
+    return P252_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-buffer entry points (synchronous)
+// ------------------------------------------------------------------------------------------
+int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!states || !out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "permute: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = n * P252_HADES_WIDTH * 32;
+    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, bytes);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, bytes);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_in, states, bytes, hipMemcpyHostToDevice));
+    rc = p252_permute_batch_device(ctx, ctx->d_in, ctx->d_out, n, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, bytes, hipMemcpyDeviceToHost));
+    return P252_OK;
+}
+
+int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
+                    uint64_t* out, size_t n) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (in_len == 0 || out_len == 0)
+        return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "hash: in_len and out_len must be > 0");
+    if (n == 0) return P252_OK;
+    if (!tag || !in || !out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "hash: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = n * in_len * 32, out_bytes = n * out_len * 32;
+    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice));
+    rc = p252_hash_batch_device(ctx, tag, ctx->d_in, in_len, out_len, ctx->d_out, n, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost));
+    return P252_OK;
+}
+
+int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                      uint64_t root[4], uint64_t* levels) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: n_leaves must be > 0");
+    if (!tag || !leaves || !root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t leaf_bytes = n_leaves * 32;
+    const size_t lvl_bytes = p252_merkle4_levels_len(n_leaves) * 32;
+    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, leaf_bytes);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, (levels ? lvl_bytes : 0) + 32);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_in, leaves, leaf_bytes, hipMemcpyHostToDevice));
+    char* d_root = static_cast<char*>(ctx->d_out);
+    char* d_levels = levels ? d_root + 32 : nullptr;
+    rc = p252_merkle4_tree_device(ctx, tag, ctx->d_in, n_leaves, d_root, d_levels, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(root, d_root, 32, hipMemcpyDeviceToHost));
+    if (levels) HIP_TRY(ctx, hipMemcpy(levels, d_levels, lvl_bytes, hipMemcpyDeviceToHost));
+    return P252_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// constant-table exchange
+// ------------------------------------------------------------------------------------------
+size_t p252_tables_size(void) { return (size_t)Tab29Layout::TOTAL * sizeof(int32_t); }
+
+int p252_tables_export(p252_ctx* ctx, void* host_buf, size_t len) {
+    if (!ctx || !host_buf || len != p252_tables_size()) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "tables_export: bad args");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(host_buf, ctx->d_tab, len, hipMemcpyDeviceToHost));
+    return P252_OK;
+}
+
+int p252_tables_import(p252_ctx* ctx, const void* host_buf, size_t len) {
+    if (!ctx || !host_buf || len != p252_tables_size()) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "tables_import: bad args");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tab, host_buf, len, hipMemcpyHostToDevice));
+    std::memcpy(ctx->h_tab.data(), host_buf, len);
+    return P252_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host helpers mirroring src/hash.rs
+// ------------------------------------------------------------------------------------------
+int p252_domain_separator(int domain, uint64_t* sep_out) {  // hash.rs:38-56
+    if (!sep_out) return P252_ERR_INVALID_ARGUMENT;
+    switch (domain) {
+        case P252_DOMAIN_MERKLE4: *sep_out = 0x000000000000000fULL; return P252_OK;
+        case P252_DOMAIN_MERKLE2: *sep_out = 0x0000000000000003ULL; return P252_OK;
+        case P252_DOMAIN_ENCRYPTION: *sep_out = 0x0000000100000000ULL; return P252_OK;
+        case P252_DOMAIN_OTHER: *sep_out = 0; return P252_OK;
+        default: return P252_ERR_INVALID_ARGUMENT;
+    }
+}
+
+int p252_check_io_pattern(int domain, const size_t* absorb_lens, size_t n_absorbs, size_t out_len) {
+    if (domain < 0 || domain > 3) return P252_ERR_INVALID_ARGUMENT;
+    if (n_absorbs && !absorb_lens) return P252_ERR_INVALID_ARGUMENT;
+    size_t total = 0;
+    for (size_t i = 0; i < n_absorbs; ++i) total += absorb_lens[i];
+    // hash.rs:70-78
+    if (domain == P252_DOMAIN_MERKLE2 && (total != 2 || out_len != 1)) return P252_ERR_IO_PATTERN_VIOLATION;
+    if (domain == P252_DOMAIN_MERKLE4 && (total != 4 || out_len != 1)) return P252_ERR_IO_PATTERN_VIOLATION;
+    // dusk-safe: a pattern must start with an absorb, end with a squeeze, and hold no zero-length call
+    if (n_absorbs == 0 || out_len == 0) return P252_ERR_INVALID_IO_PATTERN;
+    for (size_t i = 0; i < n_absorbs; ++i)
+        if (absorb_lens[i] == 0) return P252_ERR_INVALID_IO_PATTERN;
+    return P252_OK;
+}
+
+int p252_tag(int domain, const size_t* absorb_lens, size_t n_absorbs, size_t out_len, uint64_t tag_out[4]) {
+    if (!tag_out) return P252_ERR_INVALID_ARGUMENT;
+    int rc = p252_check_io_pattern(domain, absorb_lens, n_absorbs, out_len);
+    if (rc) return rc;
+    uint64_t absorbed = 0;
+    for (size_t i = 0; i < n_absorbs; ++i) absorbed += absorb_lens[i];
+    if (absorbed >= 0x80000000ULL || out_len >= 0x80000000ULL) return P252_ERR_INVALID_ARGUMENT;
+    // tag input: aggregated io-pattern words (big-endian u32, absorb flagged by the top bit), then
+    // the domain separator as a big-endian u64
+    const uint32_t words[2] = {0x80000000u | (uint32_t)absorbed, (uint32_t)out_len};
+    uint8_t buf[16];
+    for (int w = 0; w < 2; ++w)
+        for (int b = 0; b < 4; ++b) buf[4 * w + b] = (uint8_t)(words[w] >> (24 - 8 * b));
+    uint64_t sep = 0;
+    p252_domain_separator(domain, &sep);
+    for (int b = 0; b < 8; ++b) buf[8 + b] = (uint8_t)(sep >> (56 - 8 * b));
+    uint8_t h[64];
+    blake2b_512(buf, sizeof buf, h);
+    // 512-bit little-endian integer mod p:  lo + hi * 2^256
+    uint64_t lo[4], hi[4];
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = u64_from_buffer(h, 8 * k);
+        hi[k] = u64_from_buffer(h, 32 + 8 * k);
+    }
+    FrHost r = FrHost::from_raw(lo) + FrHost::from_raw(hi) * FrHost::pow2(256);
+    std::memcpy(tag_out, r.l, 32);
+    return P252_OK;
+}
+
+int p252_truncate250(const uint64_t* scalars, uint64_t* out_raw, size_t n) {  // hash.rs:164-183
+    if (n && (!scalars || !out_raw)) return P252_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) {
+        FrHost::from_limbs(scalars + 4 * i).to_canonical(out_raw + 4 * i);
+        out_raw[4 * i + 3] &= 0x03ffffffffffffffULL;
+    }
+    return P252_OK;
+}
+
+}  // extern "C"

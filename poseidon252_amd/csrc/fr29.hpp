@@ -1,0 +1,254 @@
+// fr29.hpp — BLS12-381 scalar-field arithmetic for gfx950 VALU: 9 x 29-bit limbs, 64-bit columns.
+//
+// Replaces, for batched GPU use, the BlsScalar operations the reference calls at
+// src/hades/permutation/scalar.rs:34 (add), :47 (+=), :51 (square, mul), :59 (mul, +=).
+//
+// Why this shape (measured, profiles/r01_valu_rates_gfx950.txt): on gfx950 v_mad_u64_u32 /
+// v_mad_i64_i32 issue at the same 4-cycle-per-wave rate as v_fma_f64, and v_add_co/v_addc carry
+// instructions cost exactly as much as a multiply-add.  Saturated 32-bit limbs would spend one carry
+// instruction per product; 29-bit limbs leave 6 bits of headroom per product so that a whole
+// 5-term dot product (45 products per column) accumulates in a 64-bit column with NO carry
+// instructions at all, and is Montgomery-reduced once.
+//
+// Representation ("E29"): value V = sum d[i] * 2^(29 i), d[0..7] in [0, 2^29), d[8] signed and small.
+// V is a LAZY residue: any integer congruent to x*R (R = 2^256, the reference's Montgomery radix)
+// with |V| < 4p.  Signs are tolerated everywhere (columns are signed 64-bit, multiplier constants
+// are balanced digits in [-2^28, 2^28]); only to_mont4() canonicalises to [0, p).
+//
+// Montgomery reduction here divides by R' = 2^261 (9 digits), not by R.  The mismatch
+// rho = R/R' = 2^-5 is folded into the constant tables (tables.hpp), so it costs nothing at run
+// time: redc(V * n) with n = c*R' gives (c*x)*R for V = x*R.
+//
+// All functions are __host__ __device__: the same code is unit-tested on the CPU against the
+// oracle (tests/test_host_arith.py) and runs in the kernels.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define P252_HD __host__ __device__ __forceinline__
+#else
+#define P252_HD inline __attribute__((always_inline))
+#endif
+
+namespace p252 {
+
+constexpr int NL = 9;                       // digits per element
+constexpr int WB = 29;                      // bits per digit
+constexpr uint32_t DMASK = (1u << WB) - 1;  // 0x1fffffff
+
+// p = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001 in radix 2^29.
+// p[0] == 1  =>  -p^{-1} mod 2^29 == 2^29 - 1  =>  the Montgomery quotient digit is just -t mod 2^29.
+#define P252_P29_0 0x00000001
+#define P252_P29_1 0x1ffffff8
+#define P252_P29_2 0x1f96ffbf
+#define P252_P29_3 0x1b4805ff
+#define P252_P29_4 0x1d80553b
+#define P252_P29_5 0x0c0404d0
+#define P252_P29_6 0x1520cce7
+#define P252_P29_7 0x0a6533af
+#define P252_P29_8 0x0073eda7
+
+struct E29 {
+    int32_t d[NL];
+};
+
+// 18 signed 64-bit columns: column k has weight 2^(29 k).
+struct A29 {
+    int64_t c[2 * NL];
+};
+
+P252_HD void acc_zero(A29& t) {
+#pragma unroll
+    for (int k = 0; k < 2 * NL; ++k) t.c[k] = 0;
+}
+
+// t = x * R'  (x placed in the high columns): after redc it contributes exactly x.
+P252_HD void acc_set_hi(A29& t, const E29& x) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        t.c[k] = 0;
+        t.c[NL + k] = x.d[k];
+    }
+}
+template <class CP>
+P252_HD void acc_set_hi_c(A29& t, CP c) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        t.c[k] = 0;
+        t.c[NL + k] = c[k];
+    }
+}
+template <class CP>
+P252_HD void acc_add_hi_c(A29& t, CP c) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) t.c[NL + k] += c[k];
+}
+
+// t += a * b, b = 9 digits readable as b[j] (constant-table pointer or E29::d)
+template <class BP>
+P252_HD void acc_mul(A29& t, const E29& a, BP b) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int64_t bj = b[j];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.c[i + j] += (int64_t)a.d[i] * bj;
+    }
+}
+
+// t += a * a  (45 products instead of 81)
+P252_HD void acc_sqr(A29& t, const E29& a) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        t.c[2 * i] += (int64_t)a.d[i] * (int64_t)a.d[i];
+        const int64_t a2 = (int64_t)(a.d[i] * 2);  // |d| < 2^29 -> fits int32
+#pragma unroll
+        for (int j = i + 1; j < NL; ++j) t.c[i + j] += a2 * (int64_t)a.d[j];
+    }
+}
+
+// Montgomery reduction by R' = 2^261, digit-serial.  Returns V' = (T + m p) / 2^261 with
+// 0 <= m < 2^261, so V' lies in (T/R', T/R' + p).  Output digits normalised as E29 requires.
+// Column bound: callers keep |column| < 2^63 - 2^61 before the call (see DESIGN.md "bounds").
+P252_HD E29 redc(A29& t) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const uint32_t lo = (uint32_t)t.c[i];
+        const int32_t m = (int32_t)((0u - lo) & DMASK);  // m = -t_i mod 2^29
+        // t_i + m*p[0] has its low 29 bits clear; pass the rest up as a carry
+        const int64_t carry = (t.c[i] + (int64_t)m) >> WB;
+        t.c[i + 1] += (int64_t)m * (int64_t)P252_P29_1 + carry;
+        t.c[i + 2] += (int64_t)m * (int64_t)P252_P29_2;
+        t.c[i + 3] += (int64_t)m * (int64_t)P252_P29_3;
+        t.c[i + 4] += (int64_t)m * (int64_t)P252_P29_4;
+        t.c[i + 5] += (int64_t)m * (int64_t)P252_P29_5;
+        t.c[i + 6] += (int64_t)m * (int64_t)P252_P29_6;
+        t.c[i + 7] += (int64_t)m * (int64_t)P252_P29_7;
+        t.c[i + 8] += (int64_t)m * (int64_t)P252_P29_8;
+    }
+    E29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = t.c[NL + k] + carry;
+        r.d[k] = (int32_t)((uint32_t)v & DMASK);
+        carry = v >> WB;
+    }
+    r.d[NL - 1] = (int32_t)(t.c[2 * NL - 1] + carry);
+    return r;
+}
+
+// carry-normalise an element whose digits have drifted (after digit-wise additions)
+P252_HD void normalize(E29& x) {
+    int32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int32_t v = x.d[k] + carry;
+        x.d[k] = (int32_t)((uint32_t)v & DMASK);
+        carry = v >> WB;
+    }
+    x.d[NL - 1] += carry;
+}
+
+// x += c (digit-wise; c readable as c[k]); result normalised
+template <class CP>
+P252_HD void add_c(E29& x, CP c) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) x.d[k] += c[k];
+    normalize(x);
+}
+P252_HD void add_e(E29& x, const E29& y) { add_c(x, y.d); }
+
+P252_HD E29 e29_zero() {
+    E29 r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.d[k] = 0;
+    return r;
+}
+
+// x^5 = (x^2)^2 * x  — scalar.rs:50-52.  With V = x*R the result is x^5 * R * rho^4 (rho = 2^-5);
+// the tables compensate (every constant that multiplies an S-box output carries 2^20).
+P252_HD E29 sbox(const E29& x) {
+    A29 t;
+    acc_zero(t);
+    acc_sqr(t, x);
+    const E29 x2 = redc(t);
+    acc_zero(t);
+    acc_sqr(t, x2);
+    const E29 x4 = redc(t);
+    acc_zero(t);
+    acc_mul(t, x4, x.d);
+    return redc(t);
+}
+
+// ---- conversion from / to the reference's memory format (4 x u64 Montgomery limbs, R = 2^256) ----
+// w[0..7]: the same 32 bytes viewed as 8 little-endian u32 words.
+P252_HD E29 from_mont4(const uint32_t w[8]) {
+    E29 r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int bit = WB * i;
+        const int q = bit >> 5, s = bit & 31;
+        uint64_t window = (uint64_t)w[q];
+        if (q + 1 < 8) window |= (uint64_t)w[q + 1] << 32;
+        r.d[i] = (int32_t)((uint32_t)(window >> s) & DMASK);
+    }
+    return r;
+}
+
+// Canonicalise: any lazy residue with -2p < V < 4p  ->  the unique limbs in [0, p), as the
+// reference's BlsScalar holds them (bit-exact comparison happens on these).
+P252_HD void to_mont4(const E29& x, uint32_t w[8]) {
+    // V + 2p > 0, then pack the non-negative value into 9 u32 words
+    E29 y = x;
+    const int32_t P2[NL] = {2 * P252_P29_0, 2 * P252_P29_1, 2 * P252_P29_2, 2 * P252_P29_3, 2 * P252_P29_4,
+                            2 * P252_P29_5, 2 * P252_P29_6, 2 * P252_P29_7, 2 * P252_P29_8};
+    {
+        int64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < NL - 1; ++k) {
+            const int64_t v = (int64_t)y.d[k] + P2[k] + carry;
+            y.d[k] = (int32_t)((uint32_t)v & DMASK);
+            carry = v >> WB;
+        }
+        y.d[NL - 1] = (int32_t)((int64_t)y.d[NL - 1] + P2[NL - 1] + carry);
+    }
+    uint32_t u[9];
+    {
+        // pack 9 x 29 bits into 32-bit words (value < 6p < 2^258 fits 9 words)
+        uint64_t acc = 0;
+        int bits = 0, k = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            acc |= (uint64_t)(uint32_t)y.d[i] << bits;
+            bits += WB;
+            if (bits >= 32) {
+                u[k++] = (uint32_t)acc;
+                acc >>= 32;
+                bits -= 32;
+            }
+        }
+        u[k++] = (uint32_t)acc;  // k == 9 here (261 bits -> 8 full words + remainder)
+    }
+    const uint32_t PW[9] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u,
+                            0x3339d808u, 0x299d7d48u, 0x73eda753u, 0u};
+    // subtract p while >= p: 0 < V + 2p < 6p  ->  at most 5 conditional subtractions
+#pragma unroll
+    for (int rep = 0; rep < 5; ++rep) {
+        uint32_t dif[9];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const uint64_t dd = (uint64_t)u[k] - PW[k] - borrow;
+            dif[k] = (uint32_t)dd;
+            borrow = (uint32_t)(dd >> 63);
+        }
+        const bool ge = borrow == 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) u[k] = ge ? dif[k] : u[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = u[k];
+}
+
+}  // namespace p252

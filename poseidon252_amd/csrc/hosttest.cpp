@@ -1,0 +1,94 @@
+// hosttest.cpp — CPU build of the DEVICE arithmetic headers, for unit tests only (tests/test_host_arith.py).
+// Compiles fr29.hpp / hades29.hpp / tables.hpp with g++ so the exact code the kernels run can be
+// checked against the oracle in a container without a GPU.  Not part of the product library and not
+// a CPU fallback: libposeidon252_hip.so contains none of these entry points.
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "hades29.hpp"
+#include "_gen/assets.inc"
+
+using namespace p252;
+
+static const std::vector<int32_t>& tab29() {
+    static std::vector<int32_t> t = [] {
+        HadesTables T;
+        derive_tables(ARC_BIN, MDS_BIN, T);
+        return encode_tables29(T);
+    }();
+    return t;
+}
+
+extern "C" {
+int ht_tables29_total() { return Tab29Layout::TOTAL; }
+void ht_tables29(int32_t* out) { std::memcpy(out, tab29().data(), sizeof(int32_t) * Tab29Layout::TOTAL); }
+
+// raw optimised-schedule constants as Montgomery limbs (for comparison with tests/pymodel.py)
+//  order: c_first[5], full_add[8][5], mds_pre[25], then per sparse round w[4], d, b[4], add4; last_add[4]
+size_t ht_tables_raw(uint64_t* out) {
+    HadesTables T;
+    derive_tables(ARC_BIN, MDS_BIN, T);
+    size_t k = 0;
+    auto put = [&](const FrHost& v) { std::memcpy(out + 4 * k++, v.l, 32); };
+    for (int i = 0; i < 5; ++i) put(T.c_first[i]);
+    for (int f = 0; f < 8; ++f) for (int i = 0; i < 5; ++i) put(T.full_add[f][i]);
+    for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) put(T.mds_pre[i][j]);
+    for (int q = 0; q < 60; ++q) {
+        for (int j = 0; j < 4; ++j) put(T.sparse[q].w[j]);
+        put(T.sparse[q].d);
+        for (int j = 0; j < 4; ++j) put(T.sparse[q].b[j]);
+        put(T.sparse[q].add4);
+    }
+    for (int i = 0; i < 4; ++i) put(T.last_add[i]);
+    return k;
+}
+
+void ht_roundtrip29(const uint64_t* in, uint64_t* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        E29 e = from_mont4(reinterpret_cast<const uint32_t*>(in + 4 * i));
+        to_mont4(e, reinterpret_cast<uint32_t*>(out + 4 * i));
+    }
+}
+
+// out = a * b  (both Montgomery limbs): b is encoded like a table multiplier ("MP" form)
+void ht_mul29(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    const FrHost fMP = FrHost::pow2(261);
+    for (size_t i = 0; i < n; ++i) {
+        E29 ea = from_mont4(reinterpret_cast<const uint32_t*>(a + 4 * i));
+        int32_t cb[NL];
+        encode_balanced29(FrHost::from_limbs(b + 4 * i) * fMP, cb);
+        A29 t;
+        acc_zero(t);
+        acc_mul(t, ea, cb);
+        E29 r = redc(t);
+        to_mont4(r, reinterpret_cast<uint32_t*>(out + 4 * i));
+    }
+}
+
+// out = a^5 (Montgomery limbs): S-box output carries 2^-20, undone by an "MS"-encoded one
+void ht_sbox29(const uint64_t* a, uint64_t* out, size_t n) {
+    int32_t one_ms[NL];
+    encode_balanced29(FrHost::pow2(261 + 20), one_ms);
+    for (size_t i = 0; i < n; ++i) {
+        E29 ea = from_mont4(reinterpret_cast<const uint32_t*>(a + 4 * i));
+        E29 v = sbox(ea);
+        A29 t;
+        acc_zero(t);
+        acc_mul(t, v, one_ms);
+        E29 r = redc(t);
+        to_mont4(r, reinterpret_cast<uint32_t*>(out + 4 * i));
+    }
+}
+
+void ht_permute29(const uint64_t* states, uint64_t* out, size_t n) {
+    const int32_t* tab = tab29().data();
+    for (size_t i = 0; i < n; ++i) {
+        E29 s[WIDTH];
+        for (int k = 0; k < WIDTH; ++k) s[k] = from_mont4(reinterpret_cast<const uint32_t*>(states + (i * 5 + k) * 4));
+        hades_permute(s, tab);
+        for (int k = 0; k < WIDTH; ++k) to_mont4(s[k], reinterpret_cast<uint32_t*>(out + (i * 5 + k) * 4));
+    }
+}
+}

@@ -1,0 +1,25 @@
+// kernels.h — launch interface between api.cpp (host, C ABI) and kernels.hip (device).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#ifndef P252_BLOCK
+#define P252_BLOCK 256
+#endif
+
+namespace p252 {
+
+// the sponge tag (state[0]) travels as a kernel argument: 8 x u32 = one BlsScalar
+struct TagArg {
+    uint32_t w[8];
+};
+
+hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t n, hipStream_t st);
+hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
+                          void* out, size_t n, hipStream_t st);
+hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
+                         unsigned out_len, void* out, size_t n, hipStream_t st);
+
+}  // namespace p252

@@ -1,0 +1,142 @@
+// kernels.hip — gfx950 kernels of libposeidon252_hip.so.  One sponge state per lane, the 5 x 9
+// 29-bit limbs of the state in VGPRs, 64-bit column accumulators in VGPR pairs, constants read
+// through a wave-uniform pointer (scalar loads -> SGPR operands of v_mad_i64_i32).  No LDS, no
+// cross-lane traffic, no MFMA: the path is VALU integer-multiply bound.
+//
+// Data layout in HBM: arrays of BlsScalar exactly as the reference holds them (AoS, 32 B per scalar,
+// message-major).  Each lane reads its own contiguous message with 16-byte loads; at ~1e8 perm/s the
+// whole stream is < 20 GB/s (0.3 % of HBM peak), so no staging/transposition is warranted.
+#include <hip/hip_runtime.h>
+
+#include "hades29.hpp"
+#include "kernels.h"
+
+namespace p252 {
+
+struct alignas(16) Scalar32 {
+    uint32_t w[8];
+};
+
+__device__ __forceinline__ E29 load_scalar(const Scalar32* __restrict__ p) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(p);
+    const uint4 hi = *(reinterpret_cast<const uint4*>(p) + 1);
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return from_mont4(w);
+}
+
+__device__ __forceinline__ void store_scalar(Scalar32* __restrict__ p, const E29& e) {
+    uint32_t w[8];
+    to_mont4(e, w);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(reinterpret_cast<uint4*>(p) + 1) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---- n independent permutations (Safe::permute, scalar.rs:25-27) ----
+__global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restrict__ tab,
+                                                        const Scalar32* __restrict__ in,
+                                                        Scalar32* __restrict__ out, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    E29 s[WIDTH];
+#pragma unroll
+    for (int k = 0; k < WIDTH; ++k) s[k] = load_scalar(in + idx * WIDTH + k);
+    hades_permute(s, tab);
+#pragma unroll
+    for (int k = 0; k < WIDTH; ++k) store_scalar(out + idx * WIDTH + k, s[k]);
+}
+
+// ---- Merkle4 digest: Hash::digest(Domain::Merkle4, [c0..c3]) = perm([tag, c0, c1, c2, c3])[1]
+// (hash.rs:128-155 with io-pattern [Absorb(4), Squeeze(1)]).  `n_children` may be short of 4*n:
+// missing children are the zero scalar (hash.rs:22-26). ----
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4(const int32_t* __restrict__ tab, TagArg tag,
+                                                        const Scalar32* __restrict__ children,
+                                                        size_t n_children, Scalar32* __restrict__ out,
+                                                        size_t n) {
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    E29 s[WIDTH];
+    s[0] = from_mont4(tag.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t c = idx * 4 + k;
+        if (c < n_children)
+            s[1 + k] = load_scalar(children + c);
+        else
+            s[1 + k] = e29_zero();
+    }
+    hades_permute(s, tab);
+    store_scalar(out + idx, s[1]);
+}
+
+// ---- generic sponge: n messages, same (in_len, out_len).  dusk-safe mechanics:
+// absorb 4 elements per permutation into state[1..4]; first squeeze always permutes; 4 outputs per
+// permutation.  One inlined permutation call site. ----
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict__ tab, TagArg tag,
+                                                       const Scalar32* __restrict__ in, unsigned in_len,
+                                                       unsigned out_len, Scalar32* __restrict__ out,
+                                                       size_t n) {
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const Scalar32* my_in = in + idx * in_len;
+    Scalar32* my_out = out + idx * out_len;
+    E29 s[WIDTH];
+    s[0] = from_mont4(tag.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[1 + k] = e29_zero();
+    const unsigned absorb_blocks = (in_len + 3) / 4;
+    const unsigned squeeze_blocks = (out_len + 3) / 4;
+    // block 0 of the message
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((unsigned)k < in_len) s[1 + k] = load_scalar(my_in + k);
+#pragma unroll 1
+    for (unsigned it = 1; it < absorb_blocks + squeeze_blocks; ++it) {
+        hades_permute(s, tab);
+        if (it < absorb_blocks) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned e = it * 4 + k;
+                if (e < in_len) add_e(s[1 + k], load_scalar(my_in + e));  // Safe::add, scalar.rs:33-35
+            }
+        } else {
+            const unsigned ob = (it - absorb_blocks) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ob + k < out_len) store_scalar(my_out + ob + k, s[1 + k]);
+        }
+    }
+}
+
+}  // namespace p252
+
+// ---------------------------------------------------------------------------------------------
+// launchers (C++ linkage, called from api.cpp)
+// ---------------------------------------------------------------------------------------------
+namespace p252 {
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + P252_BLOCK - 1) / P252_BLOCK); }
+
+hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_permute, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab,
+                       static_cast<const Scalar32*>(in), static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
+                          void* out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merkle4, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                       static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
+                         unsigned out_len, void* out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sponge, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                       static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+}  // namespace p252

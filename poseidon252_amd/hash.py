@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's public hash API over the C ABI.
+
+Mirrors, name for name, `dusk_poseidon::{Domain, Hash}` (src/hash.rs:21-211, re-exported at
+src/lib.rs:19-22) and adds the batched sibling `HashBatch` that the GPU needs.  The reference is a
+Rust crate; no Rust toolchain exists in this image, so this mirror is Python over ctypes (the Rust
+binding a maintainer would add is in INTEGRATION.md).  All hashing happens in
+libposeidon252_hip.so on the GPU — a missing extension or GPU raises, nothing falls back to a CPU.
+
+Scalars are numpy uint64 arrays whose last axis is the 4 little-endian limbs of a `BlsScalar`
+(Montgomery form, exactly the reference's memory layout), or torch CUDA tensors of the same bytes.
+"""
+import ctypes
+import enum
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["Domain", "Hash", "HashBatch", "Context", "Error", "IOPatternViolation", "InvalidIOPattern",
+           "HADES_WIDTH", "compute_tag"]
+
+HADES_WIDTH = 5  # dusk_poseidon::HADES_WIDTH, src/lib.rs:17
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class Error(Exception):
+    """dusk_poseidon::Error (src/error.rs:9-29) — only the variants the hash path can produce."""
+
+
+class IOPatternViolation(Error):
+    """Error::IOPatternViolation (src/error.rs:12-14): Merkle domain with the wrong arity (hash.rs:70-78)."""
+
+
+class InvalidIOPattern(Error):
+    """Error::InvalidIOPattern (src/error.rs:16-17): empty input / zero-length chunk / zero outputs."""
+
+
+class DeviceError(RuntimeError):
+    """HIP failure or no device: there is no CPU fallback."""
+
+
+def _raise(rc, ctx_handle=None):
+    msg = _lib.lib().p252_last_error(ctx_handle).decode() if ctx_handle is not None else ""
+    if rc == _lib.ERR_IO_PATTERN_VIOLATION:
+        raise IOPatternViolation("io-pattern should be valid: IOPatternViolation " + msg)
+    if rc == _lib.ERR_INVALID_IO_PATTERN:
+        raise InvalidIOPattern("at this point the io-pattern is valid: InvalidIOPattern " + msg)
+    if rc == _lib.ERR_INVALID_ARGUMENT:
+        raise ValueError("poseidon252_hip: invalid argument " + msg)
+    raise DeviceError("poseidon252_hip error %d: %s" % (rc, msg))
+
+
+class Domain(enum.IntEnum):
+    """`enum Domain` (src/hash.rs:21-36), discriminants in declaration order."""
+    Merkle4 = 0
+    Merkle2 = 1
+    Encryption = 2
+    Other = 3
+
+    def separator(self):
+        """`From<Domain> for u64` (src/hash.rs:38-56)."""
+        out = ctypes.c_uint64(0)
+        rc = _lib.lib().p252_domain_separator(int(self), ctypes.byref(out))
+        if rc:
+            _raise(rc)
+        return out.value
+
+    def __int__(self):
+        return self.value
+
+
+def check_io_pattern(domain, absorb_lens, output_len):
+    """`io_pattern()` (src/hash.rs:62-85) + dusk-safe's validation; raises like Hash::finalize panics."""
+    lens = (ctypes.c_size_t * max(1, len(absorb_lens)))(*absorb_lens)
+    rc = _lib.lib().p252_check_io_pattern(int(domain), lens, len(absorb_lens), output_len)
+    if rc:
+        _raise(rc)
+
+
+def compute_tag(domain, absorb_lens, output_len):
+    """Safe::tag for this io-pattern (scalar.rs:29-31).  UNPINNED recipe — see DESIGN.md; Rust callers
+    pass the value from the real crates instead (every entry point accepts `tag=`)."""
+    lens = (ctypes.c_size_t * max(1, len(absorb_lens)))(*absorb_lens)
+    out = np.empty(4, dtype=np.uint64)
+    rc = _lib.lib().p252_tag(int(domain), lens, len(absorb_lens), output_len, out.ctypes.data_as(_u64p))
+    if rc:
+        _raise(rc)
+    return out
+
+
+def _as_scalars(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.shape[-1] != 4:
+        raise ValueError("scalar arrays need a trailing axis of 4 u64 limbs")
+    return a
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Context:
+    """One `p252_ctx`: bound to one HIP device (one process per GPU)."""
+
+    _default = {}
+
+    def __init__(self, device=0):
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        rc = L.p252_create(int(device), ctypes.byref(h))
+        if rc:
+            raise DeviceError("p252_create(device=%d) failed (%d): %s" % (device, rc, L.p252_last_error(None).decode()))
+        self._h = h
+        self.device = int(device)
+
+    @classmethod
+    def default(cls, device=None):
+        if device is None:
+            device = 0
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    device = torch.cuda.current_device()
+            except ImportError:
+                pass
+        if device not in cls._default:
+            cls._default[device] = cls(device)
+        return cls._default[device]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().p252_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            _raise(rc, self._h)
+
+    # ---- host buffers ----
+    def permute_batch(self, states):
+        """n x [BlsScalar; 5] -> n permuted states (Safe::permute, scalar.rs:25-27)."""
+        s = _as_scalars(states).reshape(-1, 5, 4)
+        out = np.empty_like(s)
+        self._check(_lib.lib().p252_permute_batch(self._h, s.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p), s.shape[0]))
+        return out
+
+    def hash_batch(self, tag, messages, in_len, out_len):
+        tag = _as_scalars(tag).reshape(4)
+        m = _as_scalars(messages)
+        if in_len <= 0:
+            self._check(_lib.ERR_INVALID_IO_PATTERN)
+        m = m.reshape(-1, in_len, 4)
+        out = np.empty((m.shape[0], max(out_len, 0), 4), dtype=np.uint64)
+        self._check(_lib.lib().p252_hash_batch(self._h, tag.ctypes.data_as(_u64p), m.ctypes.data_as(_u64p),
+                                                in_len, out_len, out.ctypes.data_as(_u64p), m.shape[0]))
+        return out
+
+    def merkle4_tree(self, tag, leaves, want_levels=False):
+        tag = _as_scalars(tag).reshape(4)
+        lv = _as_scalars(leaves).reshape(-1, 4)
+        n = lv.shape[0]
+        root = np.empty(4, dtype=np.uint64)
+        levels = np.empty((_lib.lib().p252_merkle4_levels_len(n), 4), dtype=np.uint64) if want_levels else None
+        self._check(_lib.lib().p252_merkle4_tree(self._h, tag.ctypes.data_as(_u64p), lv.ctypes.data_as(_u64p), n,
+                                                  root.ctypes.data_as(_u64p),
+                                                  levels.ctypes.data_as(_u64p) if want_levels else None))
+        return (root, levels) if want_levels else root
+
+    # ---- device buffers (torch CUDA tensors; asynchronous on torch's current stream) ----
+    @staticmethod
+    def _stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _nbytes(t):
+        return t.numel() * t.element_size()
+
+    def permute_batch_device(self, d_states, d_out, n):
+        assert d_states.is_cuda and d_out.is_cuda and d_states.is_contiguous() and d_out.is_contiguous()
+        assert self._nbytes(d_states) >= n * 160 and self._nbytes(d_out) >= n * 160
+        self._check(_lib.lib().p252_permute_batch_device(self._h, d_states.data_ptr(), d_out.data_ptr(), n, self._stream()))
+
+    def hash_batch_device(self, tag, d_in, in_len, out_len, d_out, n):
+        tag = _as_scalars(tag).reshape(4)
+        assert d_in.is_cuda and d_out.is_cuda and d_in.is_contiguous() and d_out.is_contiguous()
+        assert self._nbytes(d_in) >= n * in_len * 32 and self._nbytes(d_out) >= n * out_len * 32
+        self._check(_lib.lib().p252_hash_batch_device(self._h, tag.ctypes.data_as(_u64p), d_in.data_ptr(), in_len, out_len,
+                                                       d_out.data_ptr(), n, self._stream()))
+
+    def merkle4_tree_device(self, tag, d_leaves, n_leaves, d_root, d_levels=None):
+        tag = _as_scalars(tag).reshape(4)
+        assert d_leaves.is_cuda and d_root.is_cuda and d_leaves.is_contiguous()
+        assert self._nbytes(d_leaves) >= n_leaves * 32 and self._nbytes(d_root) >= 32
+        if d_levels is not None:
+            assert self._nbytes(d_levels) >= _lib.lib().p252_merkle4_levels_len(n_leaves) * 32
+        self._check(_lib.lib().p252_merkle4_tree_device(self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), n_leaves,
+                                                         d_root.data_ptr(),
+                                                         d_levels.data_ptr() if d_levels is not None else None,
+                                                         self._stream()))
+
+    # ---- constant table exchange ----
+    def tables_export(self):
+        size = _lib.lib().p252_tables_size()
+        buf = np.empty(size // 4, dtype=np.int32)
+        self._check(_lib.lib().p252_tables_export(self._h, buf.ctypes.data_as(ctypes.c_void_p), size))
+        return buf
+
+    def tables_import(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.int32)
+        self._check(_lib.lib().p252_tables_import(self._h, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+
+
+def truncate250(scalars):
+    """finalize_truncated's post-processing (hash.rs:164-183): raw limbs for JubJubScalar::from_raw."""
+    s = _as_scalars(scalars)
+    out = np.empty_like(s)
+    rc = _lib.lib().p252_truncate250(s.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p), s.size // 4)
+    if rc:
+        _raise(rc)
+    return out
+
+
+class Hash:
+    """`dusk_poseidon::Hash` (src/hash.rs:87-211): one message, absorbed in chunks, squeezed once.
+
+    `tag=` overrides the capacity element (pass BlsScalar::hash_to_scalar output from the real crates)."""
+
+    def __init__(self, domain, ctx=None, tag=None):  # Hash::new, hash.rs:98-105
+        self.domain = Domain(domain)
+        self.input = []
+        self._output_len = 1
+        self._ctx = ctx
+        self._tag = tag
+
+    @classmethod
+    def new(cls, domain, **kw):
+        return cls(domain, **kw)
+
+    def output_len(self, output_len):  # hash.rs:111-115: honoured only for Domain::Other and > 0
+        if self.domain == Domain.Other and output_len > 0:
+            self._output_len = output_len
+
+    def update(self, scalars):  # hash.rs:118-120
+        self.input.append(_as_scalars(scalars).reshape(-1, 4))
+
+    def finalize(self):  # hash.rs:128-155
+        lens = [c.shape[0] for c in self.input]
+        check_io_pattern(self.domain, lens, self._output_len)  # raises where the reference panics
+        tag = self._tag if self._tag is not None else compute_tag(self.domain, lens, self._output_len)
+        msg = np.concatenate(self.input, axis=0)
+        ctx = self._ctx or Context.default()
+        return ctx.hash_batch(tag, msg[None], msg.shape[0], self._output_len)[0]
+
+    def finalize_truncated(self):  # hash.rs:164-183
+        return truncate250(self.finalize())
+
+    @classmethod
+    def digest(cls, domain, scalars, **kw):  # hash.rs:191-195
+        h = cls(domain, **kw)
+        h.update(scalars)
+        return h.finalize()
+
+    @classmethod
+    def digest_truncated(cls, domain, scalars, **kw):  # hash.rs:203-210
+        h = cls(domain, **kw)
+        h.update(scalars)
+        return h.finalize_truncated()
+
+
+class HashBatch:
+    """Batched sibling of `Hash`: n independent messages with one io-pattern, one kernel launch.
+
+    hb = HashBatch(Domain.Merkle4, item_len=4); digests = hb.digest(scalars)   # (n,4,4) -> (n,1,4)
+    Per item the result equals Hash::digest(domain, item) — same validation, same tag, same order."""
+
+    def __init__(self, domain, item_len, output_len=1, ctx=None, tag=None):
+        self.domain = Domain(domain)
+        self.item_len = int(item_len)
+        self.out_len = int(output_len) if (self.domain == Domain.Other and output_len > 0) else 1  # hash.rs:111-115
+        check_io_pattern(self.domain, [self.item_len], self.out_len)
+        self.tag = _as_scalars(tag).reshape(4) if tag is not None else compute_tag(self.domain, [self.item_len], self.out_len)
+        self._ctx = ctx
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = Context.default()
+        return self._ctx
+
+    def digest(self, scalars, out=None):
+        if _is_torch(scalars):
+            import torch
+            n = scalars.numel() * scalars.element_size() // (self.item_len * 32)
+            if out is None:
+                out = torch.empty((n, self.out_len, 4), dtype=torch.int64, device=scalars.device)
+            self.ctx.hash_batch_device(self.tag, scalars, self.item_len, self.out_len, out, n)
+            return out
+        return self.ctx.hash_batch(self.tag, scalars, self.item_len, self.out_len)
+
+    def digest_truncated(self, scalars):
+        out = self.digest(scalars)
+        if _is_torch(out):
+            out = out.cpu().numpy().view(np.uint64)
+        return truncate250(out)
