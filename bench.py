@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: width-5 Poseidon permutations/s (= Merkle4 digests/s).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+the default workload is BASELINE.json configs[1] — 2^20 independent Hash::digest(Domain::Merkle4,
+4 random BlsScalar) per GPU, one Hades permutation each, one kernel launch (k_merkle4).  Scaling is
+weak: every rank hashes its own 2^20-digest batch, no data-path collective (digests are independent);
+rank 0 broadcasts the constant table over RCCL once, before the timed region.
+
+Prints ONE JSON line (rank 0) with `roofline` (VALU int32-MAC bound — DESIGN.md §3; HBM figures are
+included, the path is not HBM- or MFMA-bound) and, at N=1, `cpu_baseline` (the C oracle, kind "port",
+timed on the host cores on a bounded sample).  The oracle is used here ONLY as the checker of a
+sample of the GPU output and as the CPU baseline; it is never the thing measured as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic figures
+MACS_PER_PERM_REFERENCE = 256_000      # 2000 field mults x 128 32x32->64 MACs (reference schedule)
+BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 12.0}
+# measured on MI355X by bench_tools/valu_rates.hip (profiles/r01_valu_rates_gfx950.txt):
+# v_mad_u64_u32 sustains 504.9 G wave-instructions/s chip-wide = 32.3e12 lane-MACs/s
+PEAK_INT32_MAC_PER_S = 504.9e9 * 64
+PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="merkle4_digests", choices=["merkle4_digests", "tree", "sponge42"])
+    ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step (default: 20; tree: 24 leaves)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(tag):
+    """The oracle (C restatement of the reference CPU path, reference schedule: 2000 mults/perm) on the
+    host cores.  Bounded sample: 2^14 digests on 1 thread, then 2^14 per thread on all threads."""
+    import oracle
+    try:  # rebuild for this host's ISA when a compiler is present (mulx/adx); fall back to the shipped build
+        import subprocess
+        native = os.path.join(ROOT, "oracle", "libp252_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-std=gnu11", "-o", native,
+                               os.path.join(ROOT, "oracle", "p252_oracle.c"), "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        oracle._LIB_PATH = native
+        oracle._lib = None
+        oracle.lib()
+        flags = "-O3 -march=native"
+    except Exception:
+        flags = "-O3 (shipped build)"
+    threads = os.cpu_count() or 1
+    n1 = 1 << 14
+    x1 = oracle.fill_random(0xc10d, 4 * n1).reshape(n1, 4, 4)
+    t0 = time.perf_counter()
+    oracle.hash_batch(tag, x1, 4, 1)
+    t1 = time.perf_counter() - t0
+    nall = n1 * threads
+    xall = np.tile(x1, (threads, 1, 1))
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.hash_batch(tag, xall, 4, 1, threads=threads)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": nall / best, "unit": "permutations/s", "cores": threads, "kind": "port",
+            "sample": "Hash::digest(Merkle4, 4 scalars): %d digests on %d threads (best of 3); 1 thread: %d digests"
+                      % (nall, threads, n1),
+            "value_1core": n1 / t1, "cpu": cpu_model, "compiler": "gcc " + flags,
+            "note": "C restatement of the reference CPU path (oracle/p252_oracle.c, reference schedule); "
+                    "the Rust reference cannot be built here (no cargo; un-vendored crates)"}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the product has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import poseidon252_amd as P
+    from poseidon252_amd import distributed as D
+    ctx = P.Context(local_rank)
+    tables_identical = D.broadcast_tables(ctx, device=dev)  # RCCL broadcast of the constants (no-op at N=1)
+
+    wl = args.workload
+    if wl == "merkle4_digests":
+        log2n = args.log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        in_scalars, perms_per_step = 4 * n, n
+        name = "2^%d independent Merkle4 digests per GPU (BASELINE configs[1])" % log2n
+    elif wl == "tree":
+        log2n = args.log2n or 24
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        in_scalars, perms_per_step = n, P.levels_len(n)
+        name = "2^%d-leaf arity-4 Merkle tree per GPU, all levels (BASELINE configs[2])" % log2n
+    else:
+        log2n = args.log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Other, 42, output_len=5, ctx=ctx)
+        in_scalars, perms_per_step = 42 * n, 12 * n
+        name = "Domain::Other sponge, 2^%d messages x 42 scalars -> 5 outputs per GPU (BASELINE configs[3])" % log2n
+    tag = hb.tag
+
+    # synthetic input generated ON the device (splitmix64-like hash of the index, top bits cleared so
+    # every scalar is < 2^254 < p: a valid Montgomery residue; the permutation cost is data-independent)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC10D + rank)
+    d_in = torch.randint(0, 2 ** 62, (in_scalars, 4), dtype=torch.int64, device=dev, generator=g)
+    if wl == "merkle4_digests":
+        d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        step = lambda: ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
+    elif wl == "tree":
+        d_out = torch.empty(4, dtype=torch.int64, device=dev)
+        step = lambda: ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
+        step()  # allocate the context-owned level scratch outside the timed region
+    else:
+        d_out = torch.empty((n, 5, 4), dtype=torch.int64, device=dev)
+        step = lambda: ctx.hash_batch_device(tag, d_in, 42, 5, d_out, n)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(args.steps):
+        step()  # launched on torch's current stream; the events below are recorded on that same stream
+        evs[i + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was just timed: a strided sample of this rank's output against the oracle
+    checked = None
+    if not args.no_check and rank == 0:
+        import oracle
+        h_in = d_in.cpu().numpy().view(np.uint64)
+        if wl == "merkle4_digests":
+            idx = np.arange(0, n, max(1, n // 512))
+            exp = oracle.hash_batch(tag, h_in.reshape(n, 4, 4)[idx], 4, 1).reshape(-1, 4)
+            got = d_out.cpu().numpy().view(np.uint64)[idx]
+        elif wl == "tree":
+            sub = 1 << 12  # the root over the first 4^6 leaves, recomputed on the GPU and on the oracle
+            exp = oracle.merkle4_tree(tag, h_in[:sub])[0]
+            got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
+        else:
+            idx = np.arange(0, n, max(1, n // 128))
+            exp = oracle.hash_batch(tag, h_in.reshape(n, 42, 4)[idx], 42, 5)
+            got = d_out.cpu().numpy().view(np.uint64).reshape(n, 5, 4)[idx]
+        checked = bool(np.array_equal(got, exp))
+        if not checked:
+            print("PARITY FAILURE: GPU output differs from the oracle", file=sys.stderr)
+            sys.exit(3)
+
+    if rank == 0:
+        total_perms = perms_per_step * args.steps * world
+        value = total_perms / elapsed
+        k_ms = float(np.mean(launch_ms))
+        per_gpu_rate = perms_per_step / (k_ms * 1e-3)
+        achieved_mac = per_gpu_rate * MACS_PER_PERM_REFERENCE
+        hbm_gbps = per_gpu_rate * BYTES_PER_PERM[wl] / 1e9
+        line = {
+            "metric": "Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact",
+            "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (9x29-bit) / int64 columns", "data": "synthetic",
+            "config": {"workload": name, "units_per_gpu_per_step": perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
+                       "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
+            "roofline": {
+                "bound": "valu-int32-mac", "kernel": "k_merkle4" if wl != "sponge42" else "k_sponge",
+                "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
+                "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
+                "note": "algorithmic MACs = 256,000 per permutation (reference schedule, SURVEY §8d) x permutations per launch / mean launch time "
+                        "(HIP events on the launch stream); peak = measured v_mad_u64_u32 issue rate (profiles/r01_valu_rates_gfx950.txt). "
+                        "The kernel executes the sparse-partial-round schedule (fewer MACs), so frac can exceed what the reference schedule could reach.",
+                "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
+                "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
+                        "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
+                "traffic": None,
+            },
+            "parity_sample_ok": checked,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tag)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,8 @@ int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, siz
 int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
                     size_t out_len, uint64_t* out, size_t n);
 /* Arity-4 Merkle tree over Hash::digest(Domain::Merkle4, [c0,c1,c2,c3]) nodes; empty child slots
- * are the zero scalar (hash.rs:22-26).  Levels are built until a single node remains.  `levels`
+ * are the zero scalar (hash.rs:22-26).  Levels are built while more than one node remains (a single
+ * leaf is its own root; a 4^k-leaf tree costs exactly k levels).  `levels`
  * (optional) receives every level above the leaves, bottom-up, p252_merkle4_levels_len(n_leaves)
  * scalars.  n_leaves == 0 -> P252_ERR_INVALID_ARGUMENT. */
 int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,

@@ -122,11 +122,10 @@ def hash_batch(tag, inp, in_len, out_len, threads=1):
 
 def levels_total(n_leaves):
     total, c = 0, n_leaves
-    while True:
+    while c > 1:
         c = (c + 3) // 4
         total += c
-        if c <= 1:
-            return total
+    return total
 
 
 def merkle4_tree(tag, leaves, want_levels=False):

@@ -369,7 +369,7 @@ long long p252o_merkle4_tree(const uint64_t tag[4], const uint64_t *leaves, size
     const uint64_t *cur = leaves;
     uint64_t *own = NULL; /* level buffer when levels == NULL */
     uint64_t *lv_out = levels;
-    do {
+    while (cur_n > 1) { /* a single leaf is its own root: a 4^k-leaf tree costs exactly k levels */
         size_t next_n = (cur_n + 3) / 4;
         uint64_t *next = levels ? lv_out : (uint64_t *)malloc(next_n * 32);
         for (size_t i = 0; i < next_n; ++i) {
@@ -385,7 +385,7 @@ long long p252o_merkle4_tree(const uint64_t tag[4], const uint64_t *leaves, size
         cur = next;
         cur_n = next_n;
         if (levels) lv_out += next_n * 4;
-    } while (cur_n > 1);
+    }
     memcpy(root, cur, 32);
     if (!levels) free(own);
     return perms;

@@ -68,8 +68,9 @@ void p252o_kat_hash(const uint8_t *inputs_le32, size_t n, uint8_t out_le32[32]);
 
 /* ---- arity-4 Merkle tree (no in-repo reference builder since 0.29.0, CHANGELOG.md:164-168;
  * composition defined in SURVEY §8a: node = digest(Merkle4,[c0..c3]); empty slots = zero) ---- */
-/* n_leaves >= 1.  Levels are built until one node remains; a level whose size is not a multiple
- * of 4 is zero-padded (hash.rs:22-26).  If levels != NULL it receives every computed level above
+/* n_leaves >= 1.  Levels are built WHILE more than one node remains (a single leaf is its own root,
+ * so a 4^k-leaf tree costs exactly k levels); a level whose size is not a multiple of 4 is
+ * zero-padded (hash.rs:22-26).  If levels != NULL it receives every computed level above
  * the leaves, concatenated bottom-up.  Returns number of permutations, or -1. */
 long long p252o_merkle4_tree(const uint64_t tag[4], const uint64_t *leaves, size_t n_leaves,
                              uint64_t root[4], uint64_t *levels);

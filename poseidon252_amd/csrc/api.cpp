@@ -169,11 +169,10 @@ int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_i
 
 size_t p252_merkle4_levels_len(size_t n_leaves) {
     size_t total = 0, c = n_leaves;
-    if (c == 0) return 0;
-    do {
+    while (c > 1) {
         c = (c + 3) / 4;
         total += c;
-    } while (c > 1);
+    }
     return total;
 }
 
@@ -196,7 +195,7 @@ int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
         if (rc) return rc;
     }
     int parity = 0;
-    do {
+    while (cur_n > 1) {  // a single leaf is its own root: a 4^k-leaf tree costs exactly k levels
         const size_t next_n = (cur_n + 3) / 4;
         char* next = d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]);
         HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st));
@@ -204,7 +203,7 @@ int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
         cur_n = next_n;
         if (d_levels) lv += next_n * 32;
         parity ^= 1;
-    } while (cur_n > 1);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
     return P252_OK;
 }

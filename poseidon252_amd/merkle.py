@@ -2,7 +2,7 @@
 
 The reference removed its tree builder in 0.29.0 (CHANGELOG.md:164-168); only the node hash
 remains (src/hash.rs:22-26: total input exactly 4 scalars, empty slots = zero scalar).  The tree is
-the obvious composition: levels are hashed until one node remains, a level whose length
+the obvious composition: levels are hashed while more than one node remains (a single leaf is its own root), a level whose length
 is not a multiple of 4 is zero-padded.
 """
 import numpy as np
@@ -16,11 +16,10 @@ def merkle4_tag():
 
 def levels_len(n_leaves):
     total, c = 0, n_leaves
-    while True:
+    while c > 1:
         c = (c + 3) // 4
         total += c
-        if c <= 1:
-            return total
+    return total
 
 
 def permutations(n_leaves):
@@ -37,7 +36,7 @@ def merkle4_tree(leaves, tag=None, ctx=None, want_levels=False):
         import torch
         n = leaves.numel() * leaves.element_size() // 32
         root = torch.empty(4, dtype=torch.int64, device=leaves.device)
-        levels = torch.empty((levels_len(n), 4), dtype=torch.int64, device=leaves.device) if want_levels else None
+        levels = torch.empty((max(levels_len(n), 1), 4), dtype=torch.int64, device=leaves.device) if want_levels else None
         ctx.merkle4_tree_device(tag, leaves, n, root, levels)
         return (root, levels) if want_levels else root
     return ctx.merkle4_tree(tag, np.asarray(leaves), want_levels=want_levels)

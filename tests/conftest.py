@@ -1,0 +1,51 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def hosttest_lib():
+    """CPU build of the device arithmetic headers (same code the kernels run)."""
+    import ctypes
+    from poseidon252_amd import build as b
+    path = b.HOSTTEST_LIB
+    if not os.path.exists(path) or os.path.exists("/usr/bin/g++"):
+        try:
+            path = b.build_hosttest()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    return ctypes.CDLL(path)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    if not _has_gpu():
+        pytest.skip("no GPU")
+    import poseidon252_amd as P
+    return P.Context(0)

@@ -1,0 +1,96 @@
+"""The DEVICE arithmetic (poseidon252_amd/csrc/fr29.hpp, hades29.hpp, tables.hpp) compiled for the
+host and checked limb-for-limb against the oracle.  Same source the kernels run; no GPU needed."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import pymodel
+
+P = pymodel.P
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def edge_scalars(oracle_mod):
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, (1 << 255) % P, (1 << 254), (1 << 29) - 1, 1 << 29,
+            (1 << 232) - 1, 1 << 232, pow(2, -256, P), pow(2, 256, P), pow(3, 200, P)]
+    mont = [oracle_mod.mont_from_int(v) for v in vals]
+    # also raw limb patterns near the modulus (any value < p is a valid Montgomery residue)
+    mont += [oracle_mod.int_to_limbs(P - 1), oracle_mod.int_to_limbs(P - (1 << 200)), oracle_mod.int_to_limbs((1 << 254) + 12345)]
+    return np.stack(mont)
+
+
+def test_roundtrip_and_canonical(oracle_mod, hosttest_lib):
+    a = np.concatenate([edge_scalars(oracle_mod), oracle_mod.fill_random(11, 3000)])
+    out = np.empty_like(a)
+    hosttest_lib.ht_roundtrip29(p(a), p(out), a.shape[0])
+    assert np.array_equal(a, out)
+
+
+def test_mul_matches_oracle(oracle_mod, hosttest_lib):
+    e = edge_scalars(oracle_mod)
+    a = np.concatenate([np.repeat(e, len(e), axis=0), oracle_mod.fill_random(12, 4000)])
+    b = np.concatenate([np.tile(e, (len(e), 1)), oracle_mod.fill_random(13, 4000)])
+    exp = np.empty_like(a)
+    for i in range(a.shape[0]):
+        oracle_mod.lib().p252o_mul(p(a[i]), p(b[i]), p(exp[i]))
+    out = np.empty_like(a)
+    hosttest_lib.ht_mul29(p(a), p(b), p(out), a.shape[0])
+    assert np.array_equal(exp, out)
+
+
+def test_sbox_matches_bigint(oracle_mod, hosttest_lib):
+    a = np.concatenate([edge_scalars(oracle_mod), oracle_mod.fill_random(14, 300)])
+    exp = np.stack([oracle_mod.mont_from_int(pow(oracle_mod.int_from_mont(v), 5, P)) for v in a])
+    out = np.empty_like(a)
+    hosttest_lib.ht_sbox29(p(a), p(out), a.shape[0])
+    assert np.array_equal(exp, out)
+
+
+def test_permutation_matches_oracle(oracle_mod, hosttest_lib):
+    e = edge_scalars(oracle_mod)
+    rng = random.Random(3)
+    special = np.stack([np.stack([e[rng.randrange(len(e))] for _ in range(5)]) for _ in range(64)])
+    st = np.concatenate([special, oracle_mod.fill_random(15, 5 * 1500).reshape(1500, 5, 4)])
+    out = np.empty_like(st)
+    hosttest_lib.ht_permute29(p(st), p(out), st.shape[0])
+    assert np.array_equal(out, oracle_mod.permute_batch(st))
+
+
+def test_tables_match_independent_derivation(oracle_mod, hosttest_lib):
+    """csrc/tables.hpp (C++) vs tests/pymodel.py (big ints): same sparse matrices and folded constants"""
+    C, M = pymodel.load_constants()
+    T = pymodel.derive_optimised(C, M)
+    n = 5 + 40 + 25 + 60 * 10 + 4
+    raw = np.empty((n, 4), dtype=np.uint64)
+    hosttest_lib.ht_tables_raw.restype = ctypes.c_size_t
+    assert hosttest_lib.ht_tables_raw(p(raw)) == n
+    got = [oracle_mod.int_from_mont(v) for v in raw]
+    exp = list(T["c_first"])
+    full_add = {0: C[1], 1: C[2], 2: C[3], 3: T["pre_add"], 4: C[65], 5: C[66], 6: C[67], 7: [0] * 5}
+    for f in range(8):
+        exp += list(full_add[f])
+    exp += [T["m_pre"][i][j] for i in range(5) for j in range(5)]
+    for q in range(60):
+        s = T["sparse"][q]
+        exp += list(s["w"]) + [s["d"]] + list(s["b"]) + [s["add"][4]]
+    exp += list(T["sparse"][59]["add"][:4])
+    assert got == exp
+
+
+def test_table_digit_bounds(hosttest_lib):
+    """every encoded constant digit is balanced (|d| <= 2^28): the column-overflow argument in
+    DESIGN.md (45 products < 2^57 each per column, plus < 2^61 from the reduction) relies on it"""
+    hosttest_lib.ht_tables29_total.restype = ctypes.c_int
+    n = hosttest_lib.ht_tables29_total()
+    tab = np.empty(n, dtype=np.int32)
+    hosttest_lib.ht_tables29(tab.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    assert n % 9 == 0 and np.abs(tab.astype(np.int64)).max() <= (1 << 28)
+    digits = tab.reshape(-1, 9).astype(object)
+    vals = [sum(int(d) << (29 * i) for i, d in enumerate(row)) for row in digits]
+    assert all(abs(v) <= P // 2 + 1 for v in vals)

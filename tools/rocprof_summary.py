@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 results.db (rocpd sqlite) into the text table kept under profiles/.
+usage: rocprof_summary.py <results.db> [title]"""
+import sqlite3
+import sys
+
+
+def main(path, title=""):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    print("# rocprofv3 --kernel-trace --stats summary%s" % ((": " + title) if title else ""))
+    print("# source db: %s" % path.split("/")[-1])
+    print("%-60s %8s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+    rows = list(cur.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc"))
+    tot = sum(r[2] for r in rows) or 1
+    for name, calls, total, avg, mn, mx in rows:
+        short = name.split("(")[0][-58:]
+        print("%-60s %8d %14.1f %12.1f %12.1f %12.1f %6.2f%%" % (short, calls, total / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * total / tot))
+    print()
+    print("# per-kernel launch geometry / registers (first dispatch)")
+    for r in cur.execute("select name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size from kernels group by name"):
+        print("%-60s grid=%d wg=%d vgpr=%s agpr=%s sgpr=%s lds=%s scratch=%s" % ((r[0].split("(")[0][-58:],) + tuple(r[1:])))
+    try:
+        rows = list(cur.execute("select name, counter_name, avg(value), sum(value), count(*) from counters_collection group by name, counter_name"))
+        if rows:
+            print()
+            print("# PMC counters (avg per dispatch, sum, dispatches)")
+            for name, cname, avg, sm, n in rows:
+                print("%-40s %-28s avg=%.4g sum=%.4g n=%d" % (name.split("(")[0][-38:], cname, avg, sm, n))
+    except sqlite3.Error:
+        pass
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
