@@ -53,6 +53,17 @@ struct E29 {
     int32_t d[NL];
 };
 
+// Hides the value range of a freshly masked digit from the optimiser.  Without it LLVM knows the
+// digit is non-negative, treats (int64)digit * (int64)signed_constant as zext x sext and lowers it to
+// TWO v_mad_u64_u32 plus two v_mov (unsigned product + sign correction) instead of ONE
+// v_mad_i64_i32 — measured: 1,200 of 3,050 instructions per partial round.  Emits no instruction.
+P252_HD int32_t opaque_digit(int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+
 // 18 signed 64-bit columns: column k has weight 2^(29 k).
 struct A29 {
     int64_t c[2 * NL];
@@ -107,31 +118,31 @@ P252_HD void acc_sqr(A29& t, const E29& a) {
     }
 }
 
-// Montgomery reduction by R' = 2^261, digit-serial.  Returns V' = (T + m p) / 2^261 with
-// 0 <= m < 2^261, so V' lies in (T/R', T/R' + p).  Output digits normalised as E29 requires.
+// Montgomery reduction by R' = 2^261, digit-serial, with a NEGATIVE quotient digit: step i subtracts
+// lo_i * p * 2^(29 i) where lo_i = t_i mod 2^29 (p[0] == 1, so column i becomes t_i - lo_i, an exact
+// multiple of 2^29 whose quotient is simply t_i >> 29 — no add, no negate, no zero-extension).
+// Returns V' = (T - m p) / 2^261 with 0 <= m < 2^261, i.e. V' in (T/R' - p, T/R'].
+// Cost per step: 1 v_and + 8 v_mad_i64_i32 + 1 v_ashrrev_i64 + 1 v_lshl_add_u64.
 // Column bound: callers keep |column| < 2^63 - 2^61 before the call (see DESIGN.md "bounds").
 P252_HD E29 redc(A29& t) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const uint32_t lo = (uint32_t)t.c[i];
-        const int32_t m = (int32_t)((0u - lo) & DMASK);  // m = -t_i mod 2^29
-        // t_i + m*p[0] has its low 29 bits clear; pass the rest up as a carry
-        const int64_t carry = (t.c[i] + (int64_t)m) >> WB;
-        t.c[i + 1] += (int64_t)m * (int64_t)P252_P29_1 + carry;
-        t.c[i + 2] += (int64_t)m * (int64_t)P252_P29_2;
-        t.c[i + 3] += (int64_t)m * (int64_t)P252_P29_3;
-        t.c[i + 4] += (int64_t)m * (int64_t)P252_P29_4;
-        t.c[i + 5] += (int64_t)m * (int64_t)P252_P29_5;
-        t.c[i + 6] += (int64_t)m * (int64_t)P252_P29_6;
-        t.c[i + 7] += (int64_t)m * (int64_t)P252_P29_7;
-        t.c[i + 8] += (int64_t)m * (int64_t)P252_P29_8;
+        const int64_t lo = opaque_digit((int32_t)((uint32_t)t.c[i] & DMASK));
+        t.c[i + 1] += (t.c[i] >> WB) - lo * (int64_t)P252_P29_1;
+        t.c[i + 2] -= lo * (int64_t)P252_P29_2;
+        t.c[i + 3] -= lo * (int64_t)P252_P29_3;
+        t.c[i + 4] -= lo * (int64_t)P252_P29_4;
+        t.c[i + 5] -= lo * (int64_t)P252_P29_5;
+        t.c[i + 6] -= lo * (int64_t)P252_P29_6;
+        t.c[i + 7] -= lo * (int64_t)P252_P29_7;
+        t.c[i + 8] -= lo * (int64_t)P252_P29_8;
     }
     E29 r;
     int64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < NL - 1; ++k) {
         const int64_t v = t.c[NL + k] + carry;
-        r.d[k] = (int32_t)((uint32_t)v & DMASK);
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
     r.d[NL - 1] = (int32_t)(t.c[2 * NL - 1] + carry);
@@ -144,7 +155,7 @@ P252_HD void normalize(E29& x) {
 #pragma unroll
     for (int k = 0; k < NL - 1; ++k) {
         const int32_t v = x.d[k] + carry;
-        x.d[k] = (int32_t)((uint32_t)v & DMASK);
+        x.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
     x.d[NL - 1] += carry;
@@ -196,7 +207,7 @@ P252_HD E29 from_mont4(const uint32_t w[8]) {
     return r;
 }
 
-// Canonicalise: any lazy residue with -2p < V < 4p  ->  the unique limbs in [0, p), as the
+// Canonicalise: any lazy residue with -2p < V < 3p  ->  the unique limbs in [0, p), as the
 // reference's BlsScalar holds them (bit-exact comparison happens on these).
 P252_HD void to_mont4(const E29& x, uint32_t w[8]) {
     // V + 2p > 0, then pack the non-negative value into 9 u32 words
