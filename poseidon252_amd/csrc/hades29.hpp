@@ -1,9 +1,11 @@
-// hades29.hpp — the Hades permutation and the SAFE sponge on E29 lazy residues (one state per lane).
+// hades29.hpp — the Hades permutation on E29 lazy residues (one state per lane).
 //
 // Replaces Hades::perm (src/hades/permutation.rs:105-123) with its ARC / S-box / MDS steps
-// (src/hades/permutation/scalar.rs:39-64) and the sponge loop dusk-safe runs for Hash::finalize
-// (src/hash.rs:128-155).  Executes the sparse-partial-round schedule whose constants
-// tables.hpp derives; the field elements produced are identical to the reference schedule's.
+// (src/hades/permutation/scalar.rs:39-64).  Two algebraically equivalent schedules, both producing
+// the reference's field elements (tables.hpp derives their constants):
+//   hades_permute_sparse  4 full | 60 sparse partial rounds (12 mults, 8 reductions each) | 4 full
+//   hades_permute         4 full | 4 sparse partial rounds | 56 "ARMA" partial rounds (12 mults,
+//                         4 reductions each) | exit (32 mults, 4 reductions) | 4 full      <- kernels
 //
 // TP is any pointer-like giving int32 digits: tab[i].  In kernels it is a wave-uniform pointer so
 // the compiler keeps constants in SGPRs (s_load) and feeds them to v_mad_i64_i32 as scalar operands.
@@ -15,6 +17,7 @@ namespace p252 {
 
 // One full round: state <- Mat * sbox(state) + add     (ARC of this round was folded into the
 // previous layer's `add`).  5 S-boxes (15 mults, 15 redc) + 25 products + 5 redc.
+// ROWS < 5 computes only the first ROWS output lanes (the last round of a digest needs lane 1 only).
 template <class TP>
 P252_HD void full_round(E29 s[WIDTH], TP mat, TP add) {
     E29 v[WIDTH];
@@ -31,9 +34,9 @@ P252_HD void full_round(E29 s[WIDTH], TP mat, TP add) {
 }
 
 // One partial round in sparse form: v = sbox(s4);  s4' = <w, s[0..3]> + d*v + add4;  s_i' = s_i + b_i*v.
-// 3 + 9 products-of-elements, 3 + 5 redc.
+// 3 + 9 products-of-elements, 3 + 5 redc.  Returns v.  AXPY=false skips the lane 0..3 update.
 template <class TP>
-P252_HD void partial_round(E29 s[WIDTH], TP sp) {
+P252_HD E29 partial_round(E29 s[WIDTH], TP sp, bool axpy = true) {
     typedef Tab29Layout Lay;
     const E29 v = sbox(s[4]);
     A29 t;
@@ -42,20 +45,22 @@ P252_HD void partial_round(E29 s[WIDTH], TP sp) {
     for (int j = 0; j < 4; ++j) acc_mul(t, s[j], sp + Lay::SP_W + j * NL);
     acc_mul(t, v, sp + Lay::SP_D);
     const E29 y4 = redc(t);
+    if (axpy) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        A29 u;
-        acc_set_hi(u, s[i]);
-        acc_mul(u, v, sp + Lay::SP_B + i * NL);
-        s[i] = redc(u);
+        for (int i = 0; i < 4; ++i) {
+            A29 u;
+            acc_set_hi(u, s[i]);
+            acc_mul(u, v, sp + Lay::SP_B + i * NL);
+            s[i] = redc(u);
+        }
     }
     s[4] = y4;
+    return v;
 }
 
-// The whole permutation as ONE loop with a wave-uniform branch, so that the (large, fully unrolled)
-// full-round and partial-round bodies each exist once in the instruction stream.
+// ---- schedule 1: all 60 partial rounds in sparse form (kept as an independent cross-check) ----
 template <class TP>
-P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
+P252_HD void hades_permute_sparse(E29 s[WIDTH], TP tab) {
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
 #pragma unroll
@@ -71,6 +76,93 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) add_c(s[i], tab + Lay::LAST_ADD + i * NL);
             }
+        }
+    }
+}
+
+// ---- schedule 2: ARMA partial rounds ----
+// History layout while in the ARMA phase (q = index of the partial round about to run, 5..60):
+//   h[0..3] = u_q, u_{q-1}, u_{q-2}, u_{q-3}      (S-box inputs, constants included)
+//   h[4..8] = v_{q-1}, v_{q-2}, v_{q-3}, v_{q-4}, (free)   -> after the S-box: v_q .. v_{q-4}
+// One step:  v_q = sbox(u_q);  u_{q+1} = sum a_m u_{q+1-m} + sum beta_n v_{q-n} + kappa_{q+1}.
+template <class TP>
+P252_HD void arma_round(E29 h[9], TP tab, int q) {
+    typedef Tab29Layout Lay;
+    // shift v history, newest first
+    h[8] = h[7];
+    h[7] = h[6];
+    h[6] = h[5];
+    h[5] = h[4];
+    h[4] = sbox(h[0]);
+    A29 t;
+    acc_set_hi_c(t, tab + Lay::ARMA_KAPPA + (q + 1 - 6) * NL);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc_mul(t, h[m], tab + Lay::ARMA_A + m * NL);
+#pragma unroll
+    for (int n = 0; n < 5; ++n) acc_mul(t, h[4 + n], tab + Lay::ARMA_BETA + n * NL);
+    const E29 unew = redc(t);
+    h[3] = h[2];
+    h[2] = h[1];
+    h[1] = h[0];
+    h[0] = unew;
+}
+
+// After round 60: h[0..3] = u_61..u_58, h[4..7] = v_60..v_57.  Recover lanes 0..3 of the state
+// (closing constants included); lane 4 = u_61.
+template <class TP>
+P252_HD void arma_exit(const E29 h[9], E29 s[WIDTH], TP tab) {
+    typedef Tab29Layout Lay;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        A29 t;
+        acc_set_hi_c(t, tab + Lay::EXIT_ADD + i * NL);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // Gy[i][r] multiplies u_{58+r} = h[3-r]; Gv[i][r] multiplies v_{57+r} = h[7-r]
+            acc_mul(t, h[3 - r], tab + Lay::EXIT_GY + (i * 4 + r) * NL);
+            acc_mul(t, h[7 - r], tab + Lay::EXIT_GV + (i * 4 + r) * NL);
+        }
+        s[i] = redc(t);
+    }
+    s[4] = h[0];
+}
+
+// One loop with a wave-uniform phase switch, so each large unrolled body exists once in the
+// instruction stream.  Phases (step): 0-3 full | 4-7 sparse (history built) | 8-63 ARMA q=5..60 |
+// 64 exit | 65-68 full.
+template <class TP>
+P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
+    typedef Tab29Layout Lay;
+    constexpr int RF = FULL_ROUNDS / 2;
+    constexpr int N_SPARSE = 4;
+    constexpr int STEP_ARMA0 = RF + N_SPARSE;                         // 8
+    constexpr int STEP_EXIT = STEP_ARMA0 + (PARTIAL_ROUNDS - N_SPARSE);  // 64
+    constexpr int STEP_END = STEP_EXIT + 1 + RF;                      // 69
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
+    E29 h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = e29_zero();
+#pragma unroll 1
+    for (int step = 0; step < STEP_END; ++step) {
+        if (step < RF || step > STEP_EXIT) {
+            const int f = step < RF ? step : step - STEP_EXIT - 1 + RF;
+            full_round(s, tab + (step == RF - 1 ? Lay::MDS_PRE : Lay::MDS), tab + Lay::FULL_ADD + f * WIDTH * NL);
+        } else if (step < STEP_ARMA0) {
+            // sparse partial rounds q = 1..4: record u_{q+1} and v_q
+            const int q = step - RF + 1;
+            const E29 v = partial_round(s, tab + Lay::SPARSE + (q - 1) * Lay::SPARSE_STRIDE, q < N_SPARSE);
+            h[7] = h[6];
+            h[6] = h[5];
+            h[5] = h[4];
+            h[4] = v;  // v_q newest first -> after q=4: h[4..7] = v_4..v_1
+            h[3] = h[2];
+            h[2] = h[1];
+            h[1] = h[0];
+            h[0] = s[4];  // u_{q+1} -> after q=4: h[0..3] = u_5..u_2
+        } else if (step < STEP_EXIT) {
+            arma_round(h, tab, step - STEP_ARMA0 + 5);
+        } else {
+            arma_exit(h, s, tab);
         }
     }
 }

@@ -82,13 +82,23 @@ void ht_sbox29(const uint64_t* a, uint64_t* out, size_t n) {
     }
 }
 
-void ht_permute29(const uint64_t* states, uint64_t* out, size_t n) {
+// schedule: 0 = ARMA (what the kernels run), 1 = all-sparse
+void ht_permute29_sched(const uint64_t* states, uint64_t* out, size_t n, int schedule) {
     const int32_t* tab = tab29().data();
     for (size_t i = 0; i < n; ++i) {
         E29 s[WIDTH];
         for (int k = 0; k < WIDTH; ++k) s[k] = from_mont4(reinterpret_cast<const uint32_t*>(states + (i * 5 + k) * 4));
-        hades_permute(s, tab);
+        if (schedule == 0)
+            hades_permute(s, tab);
+        else
+            hades_permute_sparse(s, tab);
         for (int k = 0; k < WIDTH; ++k) to_mont4(s[k], reinterpret_cast<uint32_t*>(out + (i * 5 + k) * 4));
     }
 }
+void ht_permute29(const uint64_t* states, uint64_t* out, size_t n) { ht_permute29_sched(states, out, n, 0); }
+
+// Static worst-case |column| of every lazy accumulation in the schedules, assuming state digits
+// < 2^29 (top digit < 2^24) and using the ACTUAL table constants; includes the < 2^61 the
+// reduction itself adds.  Must stay below 2^63 (tests/test_host_arith.py).
+double ht_max_column_bound29() { return max_column_bound29(tab29().data()); }
 }

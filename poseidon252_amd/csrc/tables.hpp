@@ -41,6 +41,13 @@ struct HadesTables {
     FrHost mds_pre[WIDTH][WIDTH];     // M'_1 * M, used by full round index 3
     SparseRound sparse[PARTIAL_ROUNDS];
     FrHost last_add[4];               // lanes 0..3 after the last sparse layer
+    // ---- "ARMA" form of partial rounds 5..60 (see derive_tables) ----
+    FrHost arma_a[4];                 // a_1..a_4: A^4 = a1 A^3 + a2 A^2 + a3 A + a4 I
+    FrHost arma_beta[5];              // beta_0..beta_4
+    FrHost arma_kappa[PARTIAL_ROUNDS - 4];  // kappa_6 .. kappa_61  (index q-6)
+    FrHost exit_gy[4][4];             // L_61 = Gy (u_58..u_61) + Gv (v_57..v_60) + exit_add
+    FrHost exit_gv[4][4];
+    FrHost exit_add[4];
 };
 
 inline uint64_t u64_from_buffer(const unsigned char* buf, size_t i) {  // src/hades.rs:40-51
@@ -152,6 +159,96 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
     T.full_add[RF - 1][4] = k_const[0];  // after the pre-matrix: only the first partial S-box constant
     for (int f = RF; f < FULL_ROUNDS - 1; ++f)  // closing rounds: round index f + PARTIAL
         for (int i = 0; i < WIDTH; ++i) T.full_add[f][i] = C[f + PARTIAL_ROUNDS + 1][i];
+
+    // ---- (3) ARMA form.  With M = [[A, b], [c^T, d]] the partial rounds are the 4th-order LTI system
+    //   L_{q+1} = A L_q + b v_q,   u_{q+1} = c^T L_q + d v_q + k_{q+1}   (u = S-box input, v = u^5).
+    // Cayley-Hamilton on A eliminates L:  u_{q+1} = sum a_m u_{q+1-m} + sum beta_n v_{q-n} + kappa_{q+1}
+    // for q >= 5: 9 multiplications and ONE reduction per partial round.  Rounds 1..4 run in the sparse
+    // form (they create the history); the state lanes 0..3 are recovered after round 60 through the
+    // observability matrix.  tests/pymodel.py::derive_arma is the independent big-int derivation.
+    FrHost A[4][4], bvec[4], cvec[4];
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j) A[i][j] = M[i][j];
+        bvec[i] = M[i][4];
+        cvec[i] = M[4][i];
+    }
+    const FrHost dval = M[4][4];
+    auto mat4mul = [](const FrHost X[4][4], const FrHost Y[4][4], FrHost Z[4][4]) {
+        FrHost tmp[4][4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                FrHost acc = FrHost::zero();
+                for (int k = 0; k < 4; ++k) acc = acc + X[i][k] * Y[k][j];
+                tmp[i][j] = acc;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) Z[i][j] = tmp[i][j];
+    };
+    {  // characteristic polynomial by Faddeev-LeVerrier
+        FrHost Mk4[4][4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) Mk4[i][j] = (i == j) ? FrHost::one() : FrHost::zero();
+        for (int k = 1; k <= 4; ++k) {
+            FrHost AM[4][4];
+            mat4mul(A, Mk4, AM);
+            FrHost tr = AM[0][0] + AM[1][1] + AM[2][2] + AM[3][3];
+            FrHost ck = (tr * FrHost::from_u64((uint64_t)k).inv()).neg();  // coefficient of x^(4-k)
+            T.arma_a[k - 1] = ck.neg();
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) Mk4[i][j] = (i == j) ? AM[i][j] + ck : AM[i][j];
+        }
+    }
+    FrHost powA[5][4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) powA[0][i][j] = (i == j) ? FrHost::one() : FrHost::zero();
+    for (int e = 1; e <= 4; ++e) mat4mul(powA[e - 1], A, powA[e]);
+    FrHost g[5];  // Markov parameters g_0 = d, g_i = c^T A^(i-1) b
+    g[0] = dval;
+    for (int e = 1; e <= 4; ++e) {
+        FrHost acc = FrHost::zero();
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) acc = acc + cvec[i] * powA[e - 1][i][j] * bvec[j];
+        g[e] = acc;
+    }
+    for (int n = 0; n < 5; ++n) {
+        FrHost acc = g[n];
+        for (int m = 1; m <= 4 && m <= n; ++m) acc = acc - T.arma_a[m - 1] * g[n - m];
+        T.arma_beta[n] = acc;
+    }
+    FrHost kq[PARTIAL_ROUNDS + 2];  // k_1..k_60, k_61 := closing constant of lane 4
+    for (int q = 1; q <= PARTIAL_ROUNDS; ++q) kq[q] = k_const[q - 1];
+    kq[PARTIAL_ROUNDS + 1] = closing_first[4];
+    for (int q = 6; q <= PARTIAL_ROUNDS + 1; ++q) {
+        FrHost acc = kq[q];
+        for (int m = 1; m <= 4; ++m) acc = acc - T.arma_a[m - 1] * kq[q - m];
+        T.arma_kappa[q - 6] = acc;
+    }
+    {  // exit matrices
+        FrHost O[4][4], Oinv[4][4], A4Oinv[4][4], Toep[4][4], A4OinvT[4][4];
+        for (int r = 0; r < 4; ++r)
+            for (int j = 0; j < 4; ++j) {
+                FrHost acc = FrHost::zero();
+                for (int i = 0; i < 4; ++i) acc = acc + cvec[i] * powA[r][i][j];
+                O[r][j] = acc;  // row r = c^T A^r
+            }
+        mat4_inverse(O, Oinv);
+        mat4mul(powA[4], Oinv, A4Oinv);
+        for (int r = 0; r < 4; ++r)
+            for (int c2 = 0; c2 < 4; ++c2) Toep[r][c2] = (c2 <= r) ? g[r - c2] : FrHost::zero();
+        mat4mul(A4Oinv, Toep, A4OinvT);
+        for (int i = 0; i < 4; ++i)
+            for (int s2 = 0; s2 < 4; ++s2) {
+                FrHost kb = FrHost::zero();  // (A^(3-s) b)[i]
+                for (int j = 0; j < 4; ++j) kb = kb + powA[3 - s2][i][j] * bvec[j];
+                T.exit_gv[i][s2] = kb - A4OinvT[i][s2];
+                T.exit_gy[i][s2] = A4Oinv[i][s2];
+            }
+        for (int i = 0; i < 4; ++i) {
+            FrHost acc = closing_first[i];
+            for (int r = 0; r < 4; ++r) acc = acc - T.exit_gy[i][r] * kq[58 + r];
+            T.exit_add[i] = acc;
+        }
+    }
 }
 
 // =============================================================================================
@@ -172,7 +269,13 @@ struct Tab29Layout {
     static constexpr int SP_W = 0, SP_D = 4 * NL, SP_B = 5 * NL, SP_ADD4 = 9 * NL;
     static constexpr int SPARSE_STRIDE = 10 * NL;
     static constexpr int LAST_ADD = SPARSE + PARTIAL_ROUNDS * SPARSE_STRIDE;  // [4][9] A
-    static constexpr int TOTAL = LAST_ADD + 4 * NL;
+    static constexpr int ARMA_A = LAST_ADD + 4 * NL;                          // [4][9] MP  (a_1..a_4)
+    static constexpr int ARMA_BETA = ARMA_A + 4 * NL;                         // [5][9] MS  (beta_0..beta_4)
+    static constexpr int ARMA_KAPPA = ARMA_BETA + 5 * NL;                     // [56][9] A  (kappa_6..kappa_61)
+    static constexpr int EXIT_GY = ARMA_KAPPA + (PARTIAL_ROUNDS - 4) * NL;    // [4][4][9] MP
+    static constexpr int EXIT_GV = EXIT_GY + 16 * NL;                         // [4][4][9] MS
+    static constexpr int EXIT_ADD = EXIT_GV + 16 * NL;                        // [4][9] A
+    static constexpr int TOTAL = EXIT_ADD + 4 * NL;
 };
 
 inline void encode_balanced29(const FrHost& field_value, int32_t out[NL]) {
@@ -232,7 +335,58 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
         put(base + Lay::SP_ADD4, T.sparse[q].add4, fA);
     }
     for (int i = 0; i < 4; ++i) put(Lay::LAST_ADD + i * NL, T.last_add[i], fA);
+    for (int m = 0; m < 4; ++m) put(Lay::ARMA_A + m * NL, T.arma_a[m], fMP);
+    for (int n = 0; n < 5; ++n) put(Lay::ARMA_BETA + n * NL, T.arma_beta[n], fMS);
+    for (int q = 0; q < PARTIAL_ROUNDS - 4; ++q) put(Lay::ARMA_KAPPA + q * NL, T.arma_kappa[q], fA);
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r) {
+            put(Lay::EXIT_GY + (i * 4 + r) * NL, T.exit_gy[i][r], fMP);
+            put(Lay::EXIT_GV + (i * 4 + r) * NL, T.exit_gv[i][r], fMS);
+        }
+    for (int i = 0; i < 4; ++i) put(Lay::EXIT_ADD + i * NL, T.exit_add[i], fA);
     return tab;
+}
+
+// Worst-case |column| (as a double) over every lazy accumulation the schedules perform, for the
+// ACTUAL constants in `tab`: state digits are bounded by 2^29 (top digit by 2^25: |V| < 4p), the
+// high-column initialisation by 2^30, and the reduction adds at most 2^29 * sum(p digits) + carries.
+// The kernels are correct iff this stays below 2^63.
+inline double max_column_bound29(const int32_t* tab) {
+    typedef Tab29Layout Lay;
+    const double DIG = 536870912.0 /* 2^29 */, TOP = 33554432.0 /* 2^25 */;
+    const double P_SUM = (double)P252_P29_1 + P252_P29_2 + P252_P29_3 + P252_P29_4 + P252_P29_5 + P252_P29_6 +
+                         P252_P29_7 + P252_P29_8;
+    const double REDC = DIG * P_SUM + 68719476736.0 /* carries < 2^36 */ + 1073741824.0 /* hi init 2^30 */;
+    double worst = 0;
+    auto group = [&](std::initializer_list<int> offsets) {
+        double col[2 * NL] = {0};
+        for (int off : offsets)
+            for (int j = 0; j < NL; ++j) {
+                const double cj = tab[off + j] < 0 ? -(double)tab[off + j] : (double)tab[off + j];
+                for (int i = 0; i < NL; ++i) col[i + j] += (i == NL - 1 ? TOP : DIG) * cj;
+            }
+        for (int k = 0; k < 2 * NL; ++k)
+            if (col[k] + REDC > worst) worst = col[k] + REDC;
+    };
+    for (int base : {Lay::MDS, Lay::MDS_PRE})
+        for (int k = 0; k < WIDTH; ++k)
+            group({base + (k * 5 + 0) * NL, base + (k * 5 + 1) * NL, base + (k * 5 + 2) * NL, base + (k * 5 + 3) * NL,
+                   base + (k * 5 + 4) * NL});
+    for (int q = 0; q < PARTIAL_ROUNDS; ++q) {
+        const int b = Lay::SPARSE + q * Lay::SPARSE_STRIDE;
+        group({b + Lay::SP_W, b + Lay::SP_W + NL, b + Lay::SP_W + 2 * NL, b + Lay::SP_W + 3 * NL, b + Lay::SP_D});
+        for (int i = 0; i < 4; ++i) group({b + Lay::SP_B + i * NL});
+    }
+    group({Lay::ARMA_A, Lay::ARMA_A + NL, Lay::ARMA_A + 2 * NL, Lay::ARMA_A + 3 * NL, Lay::ARMA_BETA,
+           Lay::ARMA_BETA + NL, Lay::ARMA_BETA + 2 * NL, Lay::ARMA_BETA + 3 * NL, Lay::ARMA_BETA + 4 * NL});
+    for (int i = 0; i < 4; ++i)
+        group({Lay::EXIT_GY + (i * 4 + 0) * NL, Lay::EXIT_GY + (i * 4 + 1) * NL, Lay::EXIT_GY + (i * 4 + 2) * NL,
+               Lay::EXIT_GY + (i * 4 + 3) * NL, Lay::EXIT_GV + (i * 4 + 0) * NL, Lay::EXIT_GV + (i * 4 + 1) * NL,
+               Lay::EXIT_GV + (i * 4 + 2) * NL, Lay::EXIT_GV + (i * 4 + 3) * NL});
+    // S-box: element x element (9 products of 2^29 x 2^29) and squarings (<= 4.5 * 2^59)
+    const double sbox_col = 9.0 * DIG * DIG + REDC;
+    if (sbox_col > worst) worst = sbox_col;
+    return worst;
 }
 
 }  // namespace p252

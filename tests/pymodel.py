@@ -172,3 +172,107 @@ if __name__ == "__main__":
         assert perm_reference(x, C, M) == perm_optimised(x, C, M, T)
     print("optimised schedule == reference schedule")
     print(["%064x" % v for v in perm_reference([0, 1, 2, 3, 4], C, M)])
+
+
+# ------------------------------------------------------------------------------------------------
+# "ARMA" form of the partial rounds.  With M = [[A, b], [c^T, d]] (lane 4 = the S-box lane), the
+# partial rounds are a 4th-order linear time-invariant system driven by the S-box outputs v_q:
+#     L_{q+1} = A L_q + b v_q ,   u_{q+1} = c^T L_q + d v_q + k_{q+1}      (u = S-box input)
+# Cayley-Hamilton on A (chi(x) = x^4 - a1 x^3 - a2 x^2 - a3 x - a4) eliminates L:
+#     u_{q+1} = sum_{m=1..4} a_m u_{q+1-m} + sum_{n=0..4} beta_n v_{q-n} + kappa_{q+1}      (q >= 5)
+# i.e. 9 multiplications and ONE reduction per partial round.  The first 4 partial rounds run in the
+# sparse state-space form (they also create the history), and after the last one the state lanes
+# 0..3 are recovered from the last four u and v through the observability matrix.
+# ------------------------------------------------------------------------------------------------
+def charpoly4(A):
+    """returns [a1,a2,a3,a4] with A^4 = a1 A^3 + a2 A^2 + a3 A + a4 I  (Faddeev-LeVerrier)"""
+    n = 4
+    I = [[1 if i == j else 0 for j in range(n)] for i in range(n)]
+    Mk = [row[:] for row in I]
+    coeffs = []
+    for k in range(1, n + 1):
+        AM = matmul(A, Mk)
+        ck = (-sum(AM[i][i] for i in range(n)) * pow(k, -1, P)) % P
+        coeffs.append(ck)  # coefficient of x^(n-k)
+        Mk = [[(AM[i][j] + (ck if i == j else 0)) % P for j in range(n)] for i in range(n)]
+    return [(-c) % P for c in coeffs]
+
+
+def derive_arma(C, M):
+    T = derive_optimised(C, M)
+    Rf = FULL // 2
+    A = [row[:4] for row in M[:4]]
+    b = [M[i][4] for i in range(4)]
+    c = M[4][:4]
+    d = M[4][4]
+    a = charpoly4(A)  # a[0]=a1..a[3]=a4
+    # Markov parameters g_0 = d, g_i = c^T A^(i-1) b
+    g = [d]
+    vec = b[:]
+    for _ in range(4):
+        g.append(sum(c[i] * vec[i] for i in range(4)) % P)
+        vec = matvec(A, vec)
+    beta = [(g[n] - sum(a[m - 1] * g[n - m] for m in range(1, min(4, n) + 1))) % P for n in range(5)]
+    # constants: k_q (q = 1..60) as in derive_optimised step (1); k_61 := closing constant of lane 4
+    k = [None] * 62
+    delta = [0] * 5
+    for q in range(1, PARTIAL + 1):
+        aq = [(delta[i] + C[Rf + q - 1][i]) % P for i in range(5)]
+        k[q] = aq[4]
+        delta = matvec(M, aq[:4] + [0])
+    closing = [(C[Rf + PARTIAL][i] + delta[i]) % P for i in range(5)]
+    k[61] = closing[4]
+    kappa = {q: (k[q] - sum(a[m - 1] * k[q - m] for m in range(1, 5))) % P for q in range(6, 62)}
+    # exit: L_61 = Gy * (y_58..y_61) + Gv * (v_57..v_60),  y = u - k
+    powA = [[[1 if i == j else 0 for j in range(4)] for i in range(4)]]
+    for _ in range(4):
+        powA.append(matmul(powA[-1], A))
+    O = [[sum(c[i] * powA[r][i][j] for i in range(4)) % P for j in range(4)] for r in range(4)]  # rows c^T A^r
+    Oinv = matinv(O)
+    Toep = [[(g[r - s] if s <= r else 0) for s in range(4)] for r in range(4)]  # y_{q+1+r} -= sum_s g_{r-s} v_{q+s}
+    A4Oinv = matmul(powA[4], Oinv)
+    Gy = A4Oinv
+    Kb = [[matvec(powA[3 - s], b)[i] for s in range(4)] for i in range(4)]  # columns A^(3-s) b
+    A4OinvT = matmul(A4Oinv, Toep)
+    Gv = [[(Kb[i][s] - A4OinvT[i][s]) % P for s in range(4)] for i in range(4)]
+    exit_add = [(closing[i] - sum(Gy[i][r] * k[58 + r] for r in range(4))) % P for i in range(4)]
+    return dict(T=T, a=a, beta=beta, kappa=kappa, Gy=Gy, Gv=Gv, exit_add=exit_add)
+
+
+def perm_arma(x, C=None, M=None, AR=None):
+    if C is None:
+        C, M = load_constants()
+    if AR is None:
+        AR = derive_arma(C, M)
+    T = AR["T"]
+    Rf = FULL // 2
+    x = [(x[i] + T["c_first"][i]) % P for i in range(5)]
+    for r in range(Rf):
+        x = [pow(v, 5, P) for v in x]
+        if r < Rf - 1:
+            x = [(p + q) % P for p, q in zip(matvec(M, x), T["full_add"][r])]
+        else:
+            x = [(p + q) % P for p, q in zip(matvec(T["m_pre"], x), T["pre_add"])]
+    # partial rounds 1..4 in sparse form (lane-4 value IS u_q: constants already folded in)
+    u, v = {1: x[4]}, {}
+    for q in range(1, 5):
+        s = T["sparse"][q - 1]
+        v[q] = pow(x[4], 5, P)
+        y4 = (sum(s["w"][j] * x[j] for j in range(4)) + s["d"] * v[q] + s["add"][4]) % P
+        x = [(x[i] + s["b"][i] * v[q]) % P for i in range(4)] + [y4]
+        u[q + 1] = y4
+    # ARMA rounds: u_6 .. u_61
+    for q in range(5, PARTIAL + 1):
+        v[q] = pow(u[q], 5, P)
+        u[q + 1] = (sum(AR["a"][m - 1] * u[q + 1 - m] for m in range(1, 5))
+                    + sum(AR["beta"][n] * v[q - n] for n in range(5)) + AR["kappa"][q + 1]) % P
+    # exit: lanes 0..3 from the history; lane 4 = u_61 (holds the closing constant)
+    L = [(sum(AR["Gy"][i][r] * u[58 + r] for r in range(4)) + sum(AR["Gv"][i][s] * v[57 + s] for s in range(4))
+          + AR["exit_add"][i]) % P for i in range(4)]
+    x = L + [u[61]]
+    for r in range(Rf + PARTIAL, ROUNDS):
+        x = [pow(t, 5, P) for t in x]
+        x = matvec(M, x)
+        if r < ROUNDS - 1:
+            x = [(p + q) % P for p, q in zip(x, T["full_add"][r])]
+    return x

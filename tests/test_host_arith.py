@@ -94,3 +94,31 @@ def test_table_digit_bounds(hosttest_lib):
     digits = tab.reshape(-1, 9).astype(object)
     vals = [sum(int(d) << (29 * i) for i, d in enumerate(row)) for row in digits]
     assert all(abs(v) <= P // 2 + 1 for v in vals)
+
+
+def test_both_schedules_match_oracle(oracle_mod, hosttest_lib):
+    """sparse-only and ARMA schedules are two independent derivations; both must equal the oracle"""
+    st = oracle_mod.fill_random(21, 5 * 600).reshape(600, 5, 4)
+    exp = oracle_mod.permute_batch(st)
+    for sched in (0, 1):
+        out = np.empty_like(st)
+        hosttest_lib.ht_permute29_sched(p(st), p(out), st.shape[0], sched)
+        assert np.array_equal(out, exp), "schedule %d" % sched
+
+
+def test_arma_bigint_model_equals_reference():
+    C, M = pymodel.load_constants()
+    AR = pymodel.derive_arma(C, M)
+    rng = random.Random(9)
+    for _ in range(3):
+        x = [rng.randrange(P) for _ in range(5)]
+        assert pymodel.perm_arma(x, C, M, AR) == pymodel.perm_reference(x, C, M)
+
+
+def test_static_column_bound(hosttest_lib):
+    """worst-case |column| of every lazy accumulation (9-term ARMA dot included), for the actual
+    constants, stays below 2^63: int64 columns cannot overflow for ANY input"""
+    import math
+    hosttest_lib.ht_max_column_bound29.restype = ctypes.c_double
+    b = hosttest_lib.ht_max_column_bound29()
+    assert 60 < math.log2(b) < 62.9, math.log2(b)
