@@ -1,0 +1,56 @@
+"""bench.py contract checks on the GPU box: the single JSON line at N=1, and the N>1 code path
+(launched exactly as the driver launches it, via torch.distributed.run) exercised with 2 ranks that
+SHARE the one available GPU and use gloo for the collectives (test-only env switches; on an 8-GPU
+node the driver runs it with the default nccl = RCCL backend, one rank per GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _one_json_line(out):
+    lines = [l for l in out.decode().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.decode()
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_json_line(gpu_ctx):
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                                   "--log2n", "16", "--no-cpu-baseline"], cwd=ROOT, timeout=600)
+    d = _one_json_line(out)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["parity_sample_ok"] is True
+    assert d["value"] > 1e6 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["hbm"]["frac"] < 0.05
+
+
+def test_bench_two_ranks_share_gpu_gloo(gpu_ctx):
+    env = dict(os.environ, P252_BENCH_SHARE_GPU="1", P252_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--log2n", "16"]
+    out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.DEVNULL)
+    d = _one_json_line(out)
+    assert d["n_gpus"] == 2 and d["parity_sample_ok"] is True and "cpu_baseline" not in d
+    assert "identical to local derivation: True" in d["config"]["constants"]
+    # whole-job value = 2 ranks x units / max-over-ranks time
+    assert d["value"] == pytest.approx(2 * d["config"]["units_per_gpu_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)

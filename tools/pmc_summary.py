@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSV passes (gpurun_out/pmc_*/pmc_counter_collection.csv) for one kernel.
+usage: pmc_summary.py <kernel-substring> <units_per_launch> <dir> [<dir> ...]   -> text on stdout, JSON on fd 3 if open"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def main():
+    kern, units = sys.argv[1], float(sys.argv[2])
+    agg = collections.defaultdict(list)
+    for d in sys.argv[3:]:
+        for r in csv.DictReader(open(os.path.join(d, "pmc_counter_collection.csv"))):
+            if kern in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
+    avg = {k: sum(v) / len(v) for k, v in agg.items()}
+    print("# rocprofv3 --pmc summary for kernel *%s* (avg per dispatch over %d dispatches, separate passes per counter group)" % (kern, len(next(iter(agg.values())))))
+    print("# grid=%s wg=%s vgpr=%s sgpr=%s scratch=%s lds=%s ; units (permutations) per launch = %d" % (meta + (units,)))
+    for k in sorted(avg):
+        print("%-24s %.6g" % (k, avg[k]))
+    out = {"kernel": kern, "units_per_launch": units, "counters": avg}
+    if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+        # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly half
+        # of the bytes of a wide (16 B/lane) streaming read -> doubled; WRITE_SIZE taken as is (it equals the
+        # output size to the byte here, which calibrates it for this access pattern).
+        rd = 2.0 * avg["FETCH_SIZE"] * 1024.0
+        wr = avg["WRITE_SIZE"] * 1024.0
+        out["hbm_bytes_per_launch"] = rd + wr
+        print("hbm_read_bytes (2 x FETCH_SIZE KB)   %.6g" % rd)
+        print("hbm_write_bytes (WRITE_SIZE KB)      %.6g" % wr)
+        print("hbm_bytes_per_launch                 %.6g   (algorithmic: %.6g = 160 B x units)" % (rd + wr, 160.0 * units))
+        print("traffic / algorithmic                %.3f" % ((rd + wr) / (160.0 * units)))
+    if "SQ_INSTS_VALU" in avg and "SQ_WAVES" in avg:
+        per_wave = avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]
+        out["valu_insts_per_wave"] = per_wave
+        print("VALU instructions per wave (= per 64 permutations)   %.0f" % per_wave)
+        if "GRBM_GUI_ACTIVE" in avg:
+            cyc = avg["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+            out["gpu_cycles_per_launch"] = cyc
+            print("GPU cycles per launch (GRBM_GUI_ACTIVE / 8 XCDs)     %.4g" % cyc)
+            print("VALU instructions per SIMD-cycle (1024 SIMDs)        %.3f   (a 4-cycle-class stream saturates at 0.25, 2-cycle at 0.5)" % (avg["SQ_INSTS_VALU"] / (1024.0 * cyc)))
+    try:
+        os.write(3, json.dumps(out).encode())
+    except OSError:
+        pass
+
+
+if __name__ == "__main__":
+    main()
