@@ -4,8 +4,9 @@
 // (src/hades/permutation/scalar.rs:39-64).  Two algebraically equivalent schedules, both producing
 // the reference's field elements (tables.hpp derives their constants):
 //   hades_permute_sparse  4 full | 60 sparse partial rounds (12 mults, 8 reductions each) | 4 full
-//   hades_permute         4 full | 4 sparse partial rounds | 56 "ARMA" partial rounds (12 mults,
-//                         4 reductions each) | exit (32 mults, 4 reductions) | 4 full      <- kernels
+//   hades_permute         4 full (the 4th with the entry matrix) | 4 entry rounds (3+4 mults, 4 redc)
+//                         | 56 "ARMA" partial rounds (12 mults, 4 reductions each) | exit (32 mults,
+//                         4 reductions) | 4 full                                          <- kernels
 //
 // TP is any pointer-like giving int32 digits: tab[i].  In kernels it is a wave-uniform pointer so
 // the compiler keeps constants in SGPRs (s_load) and feeds them to v_mad_i64_i32 as scalar operands.
@@ -19,12 +20,13 @@ namespace p252 {
 // previous layer's `add`).  5 S-boxes (15 mults, 15 redc) + 25 products + 5 redc.
 // ROWS < 5 computes only the first ROWS output lanes (the last round of a digest needs lane 1 only).
 template <class TP>
-P252_HD void full_round(E29 s[WIDTH], TP mat, TP add) {
+P252_HD void full_round(E29 s[WIDTH], TP mat, TP add, unsigned rows = 0x1fu) {
     E29 v[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) v[i] = sbox(s[i]);
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) {
+        if (!((rows >> k) & 1u)) continue;  // wave-uniform
         A29 t;
         acc_set_hi_c(t, add + k * NL);
 #pragma unroll
@@ -126,39 +128,66 @@ P252_HD void arma_exit(const E29 h[9], E29 s[WIDTH], TP tab) {
     s[4] = h[0];
 }
 
-// One loop with a wave-uniform phase switch, so each large unrolled body exists once in the
-// instruction stream.  Phases (step): 0-3 full | 4-7 sparse (history built) | 8-63 ARMA q=5..60 |
-// 64 exit | 65-68 full.
+// Entry rounds q = 1..4 of the partial phase.  Full round 3 (matrix MDS_ENTRY) has left the projections
+// p_q = c^T A^(q-1) L_1 + k_{q+1} in s[0..3] and u_1 in h[0]; then
+//   v_q = sbox(u_q);   u_{q+1} = p_q + sum_{n=0..3} g_n v_{q-n}      (v_j = 0 for j < 1: zero history)
+// s[0..3] rotate so that s[0] is always the current projection.
 template <class TP>
+P252_HD void entry_round(E29 s[WIDTH], E29 h[9], TP tab) {
+    typedef Tab29Layout Lay;
+    h[7] = h[6];
+    h[6] = h[5];
+    h[5] = h[4];
+    h[4] = sbox(h[0]);
+    A29 t;
+    acc_set_hi(t, s[0]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc_mul(t, h[4 + n], tab + Lay::ENTRY_G + n * NL);
+    const E29 unew = redc(t);
+    h[3] = h[2];
+    h[2] = h[1];
+    h[1] = h[0];
+    h[0] = unew;
+    s[0] = s[1];
+    s[1] = s[2];
+    s[2] = s[3];
+}
+
+// One loop with a wave-uniform phase switch, so each large unrolled body exists once in the
+// instruction stream.  Phases (step): 0-3 full (3 = entry matrix) | 4-7 entry q=1..4 | 8-63 ARMA
+// q=5..60 | 64 exit | 65-68 full.  OUT_ROWS: bit k set = lane k of the result is needed (a Merkle4
+// digest needs lane 1 only, so the last round computes 1 of its 5 rows).
+template <unsigned OUT_ROWS = 0x1fu, class TP>
 P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
-    constexpr int N_SPARSE = 4;
-    constexpr int STEP_ARMA0 = RF + N_SPARSE;                         // 8
-    constexpr int STEP_EXIT = STEP_ARMA0 + (PARTIAL_ROUNDS - N_SPARSE);  // 64
-    constexpr int STEP_END = STEP_EXIT + 1 + RF;                      // 69
+    constexpr int N_ENTRY = 4;
+    constexpr int STEP_ARMA0 = RF + N_ENTRY;                           // 8
+    constexpr int STEP_EXIT = STEP_ARMA0 + (PARTIAL_ROUNDS - N_ENTRY);  // 64
+    constexpr int STEP_END = STEP_EXIT + 1 + RF;                       // 69
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
     E29 h[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) h[i] = e29_zero();
+    // the row mask of the last round must look like a run-time value: with a visible constant the
+    // compiler peels the last iteration and emits a SECOND copy of the 50 KB full-round body
+    // (measured: 136 KB code, I-cache thrash, 2.7e8 -> 1.7e8 perm/s)
+    unsigned last_rows = OUT_ROWS;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(last_rows));
+#endif
 #pragma unroll 1
     for (int step = 0; step < STEP_END; ++step) {
         if (step < RF || step > STEP_EXIT) {
+            const bool entry = step == RF - 1;
             const int f = step < RF ? step : step - STEP_EXIT - 1 + RF;
-            full_round(s, tab + (step == RF - 1 ? Lay::MDS_PRE : Lay::MDS), tab + Lay::FULL_ADD + f * WIDTH * NL);
+            const unsigned rows = step == STEP_END - 1 ? last_rows : 0x1fu;
+            full_round(s, tab + (entry ? Lay::MDS_ENTRY : Lay::MDS),
+                       tab + (entry ? Lay::ENTRY_ADD : Lay::FULL_ADD + f * WIDTH * NL), rows);
+            if (entry) h[0] = s[4];  // u_1
         } else if (step < STEP_ARMA0) {
-            // sparse partial rounds q = 1..4: record u_{q+1} and v_q
-            const int q = step - RF + 1;
-            const E29 v = partial_round(s, tab + Lay::SPARSE + (q - 1) * Lay::SPARSE_STRIDE, q < N_SPARSE);
-            h[7] = h[6];
-            h[6] = h[5];
-            h[5] = h[4];
-            h[4] = v;  // v_q newest first -> after q=4: h[4..7] = v_4..v_1
-            h[3] = h[2];
-            h[2] = h[1];
-            h[1] = h[0];
-            h[0] = s[4];  // u_{q+1} -> after q=4: h[0..3] = u_5..u_2
+            entry_round(s, h, tab);
         } else if (step < STEP_EXIT) {
             arma_round(h, tab, step - STEP_ARMA0 + 5);
         } else {

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4(const int32_t* __restric
         else
             s[1 + k] = e29_zero();
     }
-    hades_permute(s, tab);
+    hades_permute<0x02u>(s, tab);  // only lane 1 is squeezed
     store_scalar(out + idx, s[1]);
 }
 

@@ -48,6 +48,11 @@ struct HadesTables {
     FrHost exit_gy[4][4];             // L_61 = Gy (u_58..u_61) + Gv (v_57..v_60) + exit_add
     FrHost exit_gv[4][4];
     FrHost exit_add[4];
+    // ---- direct entry into the ARMA phase: full round 3 outputs the projections p_q = c^T A^(q-1) L_1
+    //      (rows 0..3) and u_1 (row 4); then u_{q+1} = p_q + sum_{n<q} g_n v_{q-n}  for q = 1..4 ----
+    FrHost mds_entry[WIDTH][WIDTH];   // rows 0..3: (c^T A^(q-1)) * M[0..3][:], row 4: M[4][:]
+    FrHost entry_add[WIDTH];          // k_2, k_3, k_4, k_5, k_1
+    FrHost entry_g[4];                // Markov parameters g_0..g_3
 };
 
 inline uint64_t u64_from_buffer(const unsigned char* buf, size_t i) {  // src/hades.rs:40-51
@@ -249,6 +254,21 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
             T.exit_add[i] = acc;
         }
     }
+    // direct entry: row q-1 of mds_entry = (c^T A^(q-1)) * M[0..3][:]  (q = 1..4), row 4 = M[4][:]
+    for (int q = 1; q <= 4; ++q)
+        for (int j = 0; j < WIDTH; ++j) {
+            FrHost acc = FrHost::zero();
+            for (int i = 0; i < 4; ++i) {
+                FrHost pi = FrHost::zero();  // (c^T A^(q-1))[i]
+                for (int r = 0; r < 4; ++r) pi = pi + cvec[r] * powA[q - 1][r][i];
+                acc = acc + pi * M[i][j];
+            }
+            T.mds_entry[q - 1][j] = acc;
+        }
+    for (int j = 0; j < WIDTH; ++j) T.mds_entry[4][j] = M[4][j];
+    for (int q = 1; q <= 4; ++q) T.entry_add[q - 1] = kq[q + 1];
+    T.entry_add[4] = kq[1];
+    for (int n = 0; n < 4; ++n) T.entry_g[n] = g[n];
 }
 
 // =============================================================================================
@@ -275,7 +295,10 @@ struct Tab29Layout {
     static constexpr int EXIT_GY = ARMA_KAPPA + (PARTIAL_ROUNDS - 4) * NL;    // [4][4][9] MP
     static constexpr int EXIT_GV = EXIT_GY + 16 * NL;                         // [4][4][9] MS
     static constexpr int EXIT_ADD = EXIT_GV + 16 * NL;                        // [4][9] A
-    static constexpr int TOTAL = EXIT_ADD + 4 * NL;
+    static constexpr int MDS_ENTRY = EXIT_ADD + 4 * NL;                       // [5][5][9] MS
+    static constexpr int ENTRY_ADD = MDS_ENTRY + WIDTH * WIDTH * NL;          // [5][9] A
+    static constexpr int ENTRY_G = ENTRY_ADD + WIDTH * NL;                    // [4][9] MS  (g_0..g_3)
+    static constexpr int TOTAL = ENTRY_G + 4 * NL;
 };
 
 inline void encode_balanced29(const FrHost& field_value, int32_t out[NL]) {
@@ -344,6 +367,11 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
             put(Lay::EXIT_GV + (i * 4 + r) * NL, T.exit_gv[i][r], fMS);
         }
     for (int i = 0; i < 4; ++i) put(Lay::EXIT_ADD + i * NL, T.exit_add[i], fA);
+    for (int i = 0; i < WIDTH; ++i) {
+        for (int j = 0; j < WIDTH; ++j) put(Lay::MDS_ENTRY + (i * WIDTH + j) * NL, T.mds_entry[i][j], fMS);
+        put(Lay::ENTRY_ADD + i * NL, T.entry_add[i], fA);
+    }
+    for (int n = 0; n < 4; ++n) put(Lay::ENTRY_G + n * NL, T.entry_g[n], fMS);
     return tab;
 }
 
@@ -368,7 +396,8 @@ inline double max_column_bound29(const int32_t* tab) {
         for (int k = 0; k < 2 * NL; ++k)
             if (col[k] + REDC > worst) worst = col[k] + REDC;
     };
-    for (int base : {Lay::MDS, Lay::MDS_PRE})
+    group({Lay::ENTRY_G, Lay::ENTRY_G + NL, Lay::ENTRY_G + 2 * NL, Lay::ENTRY_G + 3 * NL});
+    for (int base : {Lay::MDS, Lay::MDS_PRE, Lay::MDS_ENTRY})
         for (int k = 0; k < WIDTH; ++k)
             group({base + (k * 5 + 0) * NL, base + (k * 5 + 1) * NL, base + (k * 5 + 2) * NL, base + (k * 5 + 3) * NL,
                    base + (k * 5 + 4) * NL});
