@@ -7,7 +7,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libposeidon252_hip.so")
+# P252_LIB_PATH: developer switch to A/B-test alternative builds of the SAME HIP library (kernel variants)
+LIB_PATH = os.environ.get("P252_LIB_PATH") or os.path.join(HERE, "libposeidon252_hip.so")
 
 OK = 0
 ERR_IO_PATTERN_VIOLATION = -1

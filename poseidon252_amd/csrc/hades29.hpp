@@ -14,6 +14,10 @@
 #include "fr29.hpp"
 #include "tables.hpp"
 
+#ifndef P252_ARMA_UNROLL
+#define P252_ARMA_UNROLL 4
+#endif
+
 namespace p252 {
 
 // One full round: state <- Mat * sbox(state) + add     (ARC of this round was folded into the
@@ -163,7 +167,9 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     constexpr int RF = FULL_ROUNDS / 2;
     constexpr int N_ENTRY = 4;
     constexpr int STEP_ARMA0 = RF + N_ENTRY;                           // 8
-    constexpr int STEP_EXIT = STEP_ARMA0 + (PARTIAL_ROUNDS - N_ENTRY);  // 64
+    constexpr int ARMA_UNROLL = P252_ARMA_UNROLL;  // ARMA rounds per loop step (history shifts become renames)
+    static_assert((PARTIAL_ROUNDS - N_ENTRY) % ARMA_UNROLL == 0, "56 ARMA rounds must split evenly");
+    constexpr int STEP_EXIT = STEP_ARMA0 + (PARTIAL_ROUNDS - N_ENTRY) / ARMA_UNROLL;
     constexpr int STEP_END = STEP_EXIT + 1 + RF;                       // 69
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
@@ -189,7 +195,8 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
         } else if (step < STEP_ARMA0) {
             entry_round(s, h, tab);
         } else if (step < STEP_EXIT) {
-            arma_round(h, tab, step - STEP_ARMA0 + 5);
+#pragma unroll
+            for (int r = 0; r < ARMA_UNROLL; ++r) arma_round(h, tab, (step - STEP_ARMA0) * ARMA_UNROLL + r + 5);
         } else {
             arma_exit(h, s, tab);
         }
