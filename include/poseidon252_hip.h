@@ -96,6 +96,22 @@ int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
                              void* d_root, void* d_levels, void* hip_stream);
 int p252_sync(p252_ctx* ctx, void* hip_stream);
 
+/* ---- SURVEY §8(f) "next" rows ---- */
+/* finalize_truncated's post-processing (hash.rs:164-183) on n device-resident BlsScalars: canonical
+ * value & (2^250 - 1), written as the raw limbs JubJubScalar::from_raw receives.  d_out_raw may alias
+ * d_scalars. */
+int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_raw, size_t n, void* hip_stream);
+/* Batched Merkle openings (arity 4): recompute the root from a leaf and its sibling path — the branch
+ * re-hash a `poseidon-merkle` verifier performs (AGENTS.md:62-66 names the downstream crate).  Per
+ * level l, node = Hash::digest(Domain::Merkle4, children) where children[positions[l]] is the value
+ * coming from below and the 3 siblings fill the other slots in order.  Layouts: leaves[n],
+ * siblings[n][depth][3] scalars, positions[n][depth] bytes in 0..3, roots[n].  depth == 0 copies the
+ * leaves.  positions outside 0..3 -> P252_ERR_INVALID_ARGUMENT (host variant; the device variant masks). */
+int p252_merkle4_path_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, const uint64_t* siblings,
+                            const uint8_t* positions, size_t depth, uint64_t* roots, size_t n);
+int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                   const void* d_positions, size_t depth, void* d_roots, size_t n, void* hip_stream);
+
 /* ---- constant-table exchange (multi-GPU: rank 0 broadcasts its derived table over RCCL, every
  * rank imports it; byte-identical to what p252_create derives locally) ---- */
 size_t p252_tables_size(void);

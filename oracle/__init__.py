@@ -140,6 +140,22 @@ def merkle4_tree(tag, leaves, want_levels=False):
     return (root, levels, perms) if want_levels else (root, perms)
 
 
+def merkle4_path_batch(tag, leaves, siblings, positions):
+    tag = _c(tag).reshape(4)
+    leaves = _c(leaves).reshape(-1, 4)
+    n = leaves.shape[0]
+    positions = np.ascontiguousarray(positions, dtype=np.uint8).reshape(n, -1)
+    depth = positions.shape[1]
+    siblings = _c(siblings).reshape(n, depth, 3, 4) if depth else np.zeros((n, 0, 3, 4), dtype=np.uint64)
+    roots = np.empty((n, 4), dtype=np.uint64)
+    f = lib().p252o_merkle4_path_batch
+    f.argtypes = [_u64p, _u64p, _u64p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t, _u64p, ctypes.c_size_t]
+    f.restype = ctypes.c_int
+    if f(_p(tag), _p(leaves), _p(siblings), positions.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), depth, _p(roots), n):
+        raise ValueError("position outside 0..3")
+    return roots
+
+
 def kat_hash(inputs_le32):
     """inputs: list of 32-byte little-endian canonical strings -> 32-byte LE canonical digest"""
     buf = b"".join(inputs_le32)

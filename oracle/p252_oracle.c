@@ -391,6 +391,33 @@ long long p252o_merkle4_tree(const uint64_t tag[4], const uint64_t *leaves, size
     return perms;
 }
 
+/* Merkle opening: re-hash a branch.  children = the 3 siblings with the running value inserted at
+ * slot positions[l]; node = digest(Merkle4, children) (hash.rs:22-26 composition). */
+int p252o_merkle4_path_batch(const uint64_t tag[4], const uint64_t *leaves, const uint64_t *siblings,
+                             const uint8_t *positions, size_t depth, uint64_t *roots, size_t n) {
+    ensure_constants();
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t cur[4];
+        memcpy(cur, leaves + 4 * i, 32);
+        for (size_t l = 0; l < depth; ++l) {
+            unsigned p = positions[i * depth + l];
+            if (p > 3) return -1;
+            const uint64_t *sib = siblings + ((i * depth + l) * 3) * 4;
+            uint64_t in[16];
+            unsigned s = 0;
+            for (unsigned k = 0; k < 4; ++k) {
+                if (k == p)
+                    memcpy(in + 4 * k, cur, 32);
+                else
+                    memcpy(in + 4 * k, sib + 4 * (s++), 32);
+            }
+            p252o_sponge(tag, in, 4, cur, 1);
+        }
+        memcpy(roots + 4 * i, cur, 32);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Domain / io_pattern  (src/hash.rs:38-85)
  * ------------------------------------------------------------------------------------------ */

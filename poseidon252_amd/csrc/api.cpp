@@ -271,6 +271,57 @@ int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leav
 }
 
 // ------------------------------------------------------------------------------------------
+// SURVEY §8(f) "next" rows: truncated outputs and batched Merkle openings
+// ------------------------------------------------------------------------------------------
+int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_raw, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!d_scalars || !d_out_raw) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "truncate250: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_truncate250(d_scalars, d_out_raw, n, (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                   const void* d_positions, size_t depth, void* d_roots, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!tag || !d_leaves || !d_roots || (depth && (!d_siblings || !d_positions)))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: NULL buffer");
+    if (depth > 0xffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: depth too large");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_merkle4_path(ctx->d_tab, tag_arg(tag), d_leaves, d_siblings, d_positions, (unsigned)depth,
+                                     d_roots, n, (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+int p252_merkle4_path_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, const uint64_t* siblings,
+                            const uint8_t* positions, size_t depth, uint64_t* roots, size_t n) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!tag || !leaves || !roots || (depth && (!siblings || !positions)))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: NULL buffer");
+    for (size_t i = 0; i < n * depth; ++i)
+        if (positions[i] > 3) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: position outside 0..3");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t leaf_b = n * 32, sib_b = n * depth * 96, pos_b = (n * depth + 15) & ~(size_t)15;
+    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, leaf_b + sib_b + pos_b + 16);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, leaf_b);
+    if (rc) return rc;
+    char* base = static_cast<char*>(ctx->d_in);
+    HIP_TRY(ctx, hipMemcpy(base, leaves, leaf_b, hipMemcpyHostToDevice));
+    if (depth) {
+        HIP_TRY(ctx, hipMemcpy(base + leaf_b, siblings, sib_b, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(base + leaf_b + sib_b, positions, n * depth, hipMemcpyHostToDevice));
+    }
+    rc = p252_merkle4_path_batch_device(ctx, tag, base, base + leaf_b, base + leaf_b + sib_b, depth, ctx->d_out, n, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(roots, ctx->d_out, leaf_b, hipMemcpyDeviceToHost));
+    return P252_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // constant-table exchange
 // ------------------------------------------------------------------------------------------
 size_t p252_tables_size(void) { return (size_t)Tab29Layout::TOTAL * sizeof(int32_t); }

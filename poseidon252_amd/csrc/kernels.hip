@@ -107,6 +107,61 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
     }
 }
 
+// ---- finalize_truncated post-processing (hash.rs:164-183) on device-resident digests:
+// canonical value (Montgomery form dropped) & (2^250 - 1), written as the raw limbs that
+// JubJubScalar::from_raw receives.  redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256 = the canonical value. ----
+__global__ void __launch_bounds__(P252_BLOCK) k_truncate250(const Scalar32* __restrict__ in,
+                                                            Scalar32* __restrict__ out, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const E29 x = load_scalar(in + idx);
+    const int32_t c32[NL] = {32, 0, 0, 0, 0, 0, 0, 0, 0};
+    A29 t;
+    acc_zero(t);
+    acc_mul(t, x, c32);
+    const E29 canon = redc(t);
+    uint32_t w[8];
+    to_mont4(canon, w);
+    w[7] &= 0x03ffffffu;  // TRUNCATION_MASK: keep the low 250 bits
+    *reinterpret_cast<uint4*>(out + idx) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(reinterpret_cast<uint4*>(out + idx) + 1) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---- batched Merkle opening: recompute the root from a leaf and its sibling path (arity 4).
+// Per level l the node hashed is Hash::digest(Merkle4, children) with children[pos[l]] = current value
+// and the 3 siblings in the remaining slots in order; depth sequential permutations per lane.
+// Layout: leaves[n], siblings[n][depth][3], positions[n][depth] (u8, 0..3), roots[n]. ----
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path(const int32_t* __restrict__ tab, TagArg tag,
+                                                             const Scalar32* __restrict__ leaves,
+                                                             const Scalar32* __restrict__ siblings,
+                                                             const uint8_t* __restrict__ positions,
+                                                             unsigned depth, Scalar32* __restrict__ roots,
+                                                             size_t n) {
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    E29 cur = load_scalar(leaves + idx);
+    const Scalar32* sib = siblings + idx * depth * 3;
+    const uint8_t* pos = positions + idx * depth;
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; ++l) {
+        const unsigned p = pos[l] & 3u;
+        E29 s[WIDTH];
+        s[0] = from_mont4(tag.w);
+        const E29 a = load_scalar(sib + l * 3 + 0), b = load_scalar(sib + l * 3 + 1), c = load_scalar(sib + l * 3 + 2);
+        // children = siblings with `cur` inserted at slot p (per-lane select, no divergence)
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            s[1].d[k] = p == 0 ? cur.d[k] : a.d[k];
+            s[2].d[k] = p == 1 ? cur.d[k] : (p < 1 ? a.d[k] : b.d[k]);
+            s[3].d[k] = p == 2 ? cur.d[k] : (p < 2 ? b.d[k] : c.d[k]);
+            s[4].d[k] = p == 3 ? cur.d[k] : c.d[k];
+        }
+        hades_permute<0x02u>(s, tab);
+        cur = s[1];
+    }
+    store_scalar(roots + idx, cur);
+}
+
 }  // namespace p252
 
 // ---------------------------------------------------------------------------------------------
@@ -136,6 +191,22 @@ hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, 
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_sponge, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                        static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_truncate250(const void* in, void* out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_truncate250, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, static_cast<const Scalar32*>(in),
+                       static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_merkle4_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings,
+                               const void* positions, unsigned depth, void* roots, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merkle4_path, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                       static_cast<const Scalar32*>(leaves), static_cast<const Scalar32*>(siblings),
+                       static_cast<const uint8_t*>(positions), depth, static_cast<Scalar32*>(roots), n);
     return hipGetLastError();
 }
 

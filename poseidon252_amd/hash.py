@@ -206,6 +206,35 @@ class Context:
                                                          d_levels.data_ptr() if d_levels is not None else None,
                                                          self._stream()))
 
+    # ---- truncated outputs on the device, batched Merkle openings ----
+    def truncate250_device(self, d_scalars, d_out, n):
+        assert d_scalars.is_cuda and d_out.is_cuda and self._nbytes(d_scalars) >= n * 32 and self._nbytes(d_out) >= n * 32
+        self._check(_lib.lib().p252_truncate250_device(self._h, d_scalars.data_ptr(), d_out.data_ptr(), n, self._stream()))
+
+    def merkle4_path_batch(self, tag, leaves, siblings, positions):
+        """leaves (n,4) u64; siblings (n,depth,3,4) u64; positions (n,depth) u8 in 0..3 -> roots (n,4)"""
+        tag = _as_scalars(tag).reshape(4)
+        lv = _as_scalars(leaves).reshape(-1, 4)
+        n = lv.shape[0]
+        pos = np.ascontiguousarray(positions, dtype=np.uint8).reshape(n, -1)
+        depth = pos.shape[1]
+        sib = _as_scalars(siblings).reshape(n, depth, 3, 4) if depth else np.zeros((n, 0, 3, 4), dtype=np.uint64)
+        roots = np.empty((n, 4), dtype=np.uint64)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        self._check(_lib.lib().p252_merkle4_path_batch(self._h, tag.ctypes.data_as(_u64p), lv.ctypes.data_as(_u64p),
+                                                        sib.ctypes.data_as(_u64p), pos.ctypes.data_as(u8p), depth,
+                                                        roots.ctypes.data_as(_u64p), n))
+        return roots
+
+    def merkle4_path_batch_device(self, tag, d_leaves, d_siblings, d_positions, depth, d_roots, n):
+        tag = _as_scalars(tag).reshape(4)
+        assert d_leaves.is_cuda and d_roots.is_cuda and self._nbytes(d_leaves) >= n * 32 and self._nbytes(d_roots) >= n * 32
+        if depth:
+            assert self._nbytes(d_siblings) >= n * depth * 96 and self._nbytes(d_positions) >= n * depth
+        self._check(_lib.lib().p252_merkle4_path_batch_device(
+            self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), d_siblings.data_ptr() if depth else None,
+            d_positions.data_ptr() if depth else None, depth, d_roots.data_ptr(), n, self._stream()))
+
     # ---- constant table exchange ----
     def tables_export(self):
         size = _lib.lib().p252_tables_size()
@@ -306,7 +335,9 @@ class HashBatch:
         return self.ctx.hash_batch(self.tag, scalars, self.item_len, self.out_len)
 
     def digest_truncated(self, scalars):
+        """Hash::digest_truncated (hash.rs:203-210) per item; device tensors are truncated on the device"""
         out = self.digest(scalars)
         if _is_torch(out):
-            out = out.cpu().numpy().view(np.uint64)
+            self.ctx.truncate250_device(out, out, out.numel() // 4)
+            return out
         return truncate250(out)

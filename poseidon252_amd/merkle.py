@@ -2,8 +2,12 @@
 
 The reference removed its tree builder in 0.29.0 (CHANGELOG.md:164-168); only the node hash
 remains (src/hash.rs:22-26: total input exactly 4 scalars, empty slots = zero scalar).  The tree is
-the obvious composition: levels are hashed while more than one node remains (a single leaf is its own root), a level whose length
-is not a multiple of 4 is zero-padded.
+the obvious composition: levels are hashed while more than one node remains (a single
+leaf is its own root), a level whose length is not a multiple of 4 is zero-padded.
+
+Openings (the `poseidon-merkle` use named in AGENTS.md:62-66): an opening of leaf
+i is, per level, the 3 siblings of the node on the path and the node's position 0..3 among its
+parent's children; `merkle4_path_roots` re-hashes n such branches in one kernel launch.
 """
 import numpy as np
 
@@ -40,3 +44,40 @@ def merkle4_tree(leaves, tag=None, ctx=None, want_levels=False):
         ctx.merkle4_tree_device(tag, leaves, n, root, levels)
         return (root, levels) if want_levels else root
     return ctx.merkle4_tree(tag, np.asarray(leaves), want_levels=want_levels)
+
+
+def merkle4_openings(leaves, levels, indices):
+    """Host-side bookkeeping (no hashing): sibling paths of the leaves at `indices` out of a built tree.
+    leaves (n,4), levels = concatenated upper levels as merkle4_tree(..., want_levels=True) returns.
+    Returns (siblings (m,depth,3,4) uint64, positions (m,depth) uint8); missing siblings = zero scalar."""
+    leaves = _as_scalars(leaves).reshape(-1, 4)
+    levels = _as_scalars(levels).reshape(-1, 4)
+    per_level, cnt, off = [leaves], leaves.shape[0], 0
+    while cnt > 1:
+        cnt = (cnt + 3) // 4
+        per_level.append(levels[off:off + cnt])
+        off += cnt
+    depth = len(per_level) - 1
+    idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+    sib = np.zeros((idx.shape[0], depth, 3, 4), dtype=np.uint64)
+    pos = np.zeros((idx.shape[0], depth), dtype=np.uint8)
+    cur = idx.copy()
+    for l in range(depth):
+        nodes = per_level[l]
+        p = cur & 3
+        pos[:, l] = p
+        base = cur - p
+        for m in range(idx.shape[0]):
+            others = [base[m] + k for k in range(4) if k != p[m]]
+            for s, j in enumerate(others):
+                if j < nodes.shape[0]:
+                    sib[m, l, s] = nodes[j]
+        cur = cur >> 2
+    return sib, pos
+
+
+def merkle4_path_roots(leaves, siblings, positions, tag=None, ctx=None):
+    """Roots recomputed from n openings (numpy host buffers); compare with the tree root to verify."""
+    ctx = ctx or Context.default()
+    tag = merkle4_tag() if tag is None else _as_scalars(tag).reshape(4)
+    return ctx.merkle4_path_batch(tag, leaves, siblings, positions)

@@ -1,0 +1,109 @@
+"""SURVEY §8(f) "next" rows: truncated outputs (hash.rs:164-183) on the device, and batched Merkle
+openings (branch re-hash, the poseidon-merkle use named in AGENTS.md:62-66)."""
+import numpy as np
+import pytest
+
+
+# ------------------------------------------------------------------ CPU: oracle + host bookkeeping
+def test_oracle_openings_reproduce_root(oracle_mod):
+    """an opening extracted from the built tree re-hashes to the tree's root (oracle only, no GPU)"""
+    from poseidon252_amd.merkle import merkle4_openings
+    tag = oracle_mod.tag(0, [4], 1)
+    for n in (1, 4, 5, 16, 21, 64, 257):
+        lv = oracle_mod.fill_random(0x900 + n, n)
+        root, levels, _ = oracle_mod.merkle4_tree(tag, lv, want_levels=True)
+        idx = sorted(set([0, n - 1, n // 2, n // 3]))
+        sib, pos = merkle4_openings(lv, levels, idx)
+        roots = oracle_mod.merkle4_path_batch(tag, lv[idx], sib, pos)
+        assert all(np.array_equal(r, root) for r in roots), n
+        if n > 1:  # a tampered leaf or a wrong position must not verify
+            bad = lv[idx].copy()
+            bad[0, 0] ^= np.uint64(1)
+            assert not np.array_equal(oracle_mod.merkle4_path_batch(tag, bad, sib, pos)[0], root)
+            pos2 = pos.copy()
+            pos2[0, 0] = (pos2[0, 0] + 1) & 3
+            assert not np.array_equal(oracle_mod.merkle4_path_batch(tag, lv[idx], sib, pos2)[0], root)
+
+
+def test_oracle_path_rejects_bad_position(oracle_mod):
+    z = np.zeros((1, 4), dtype=np.uint64)
+    with pytest.raises(ValueError):
+        oracle_mod.merkle4_path_batch(z[0], z, np.zeros((1, 1, 3, 4), dtype=np.uint64), np.array([[4]], dtype=np.uint8))
+
+
+# ------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+def test_truncate250_device_matches_reference_rule(gpu_ctx, oracle_mod):
+    import torch
+    P = oracle_mod.P
+    vals = [0, 1, P - 1, (1 << 250) - 1, 1 << 250, (1 << 250) + 5, (1 << 254), pow(2, -256, P)]
+    x = np.concatenate([np.stack([oracle_mod.mont_from_int(v) for v in vals]), oracle_mod.fill_random(0x250, 5000)])
+    d = torch.from_numpy(x.view(np.int64)).cuda()
+    out = torch.empty_like(d)
+    gpu_ctx.truncate250_device(d, out, x.shape[0])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    exp = np.stack([oracle_mod.truncate250(v) for v in x])
+    assert np.array_equal(got, exp)
+    # definition check against big ints: canonical value & (2^250 - 1)
+    for v, g in zip(vals, got):
+        assert oracle_mod.limbs_to_int(g) == (v % P) & ((1 << 250) - 1)
+    gpu_ctx.truncate250_device(d, d, x.shape[0])  # in place
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), exp)
+
+
+@pytest.mark.gpu
+def test_digest_truncated_batch_like_reference(gpu_ctx, oracle_mod):
+    """tests/hash.rs:188-203 shape (5 inputs, truncated) — batched, host and device buffers"""
+    import torch
+    import poseidon252_amd as P
+    hb = P.HashBatch(P.Domain.Other, 5, ctx=gpu_ctx)
+    m = oracle_mod.fill_random(0xbeef, 5 * 300).reshape(300, 5, 4)
+    exp = np.stack([oracle_mod.truncate250(v) for v in oracle_mod.hash_batch(hb.tag, m, 5, 1).reshape(-1, 4)]).reshape(300, 1, 4)
+    assert np.array_equal(hb.digest_truncated(m), exp)
+    d = hb.digest_truncated(torch.from_numpy(m.view(np.int64)).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), exp)
+    single = P.Hash.digest_truncated(P.Domain.Other, m[0], ctx=gpu_ctx)
+    assert np.array_equal(single, exp[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_leaves", [1, 4, 21, 256, 4099])
+def test_merkle_openings_on_gpu(gpu_ctx, oracle_mod, n_leaves):
+    from poseidon252_amd.merkle import merkle4_openings, merkle4_path_roots
+    tag = oracle_mod.tag(0, [4], 1)
+    lv = oracle_mod.fill_random(0xa00 + n_leaves, n_leaves)
+    root, levels = gpu_ctx.merkle4_tree(tag, lv, want_levels=True)
+    rng = np.random.default_rng(n_leaves)
+    idx = rng.integers(0, n_leaves, size=min(n_leaves, 700))
+    sib, pos = merkle4_openings(lv, levels, idx)
+    roots = merkle4_path_roots(lv[idx], sib, pos, tag=tag, ctx=gpu_ctx)
+    assert np.array_equal(roots, oracle_mod.merkle4_path_batch(tag, lv[idx], sib, pos))
+    assert all(np.array_equal(r, root) for r in roots)
+
+
+@pytest.mark.gpu
+def test_merkle_path_random_and_device_api(gpu_ctx, oracle_mod):
+    """arbitrary (not tree-derived) paths, depth 0..12, host and device entry points"""
+    import torch
+    import poseidon252_amd as P
+    tag = oracle_mod.fill_random(5, 1)[0]
+    for depth in (0, 1, 3, 12):
+        n = 513
+        leaves = oracle_mod.fill_random(100 + depth, n)
+        sib = oracle_mod.fill_random(200 + depth, n * depth * 3).reshape(n, depth, 3, 4) if depth else np.zeros((n, 0, 3, 4), dtype=np.uint64)
+        pos = np.random.default_rng(depth).integers(0, 4, size=(n, depth)).astype(np.uint8)
+        exp = oracle_mod.merkle4_path_batch(tag, leaves, sib, pos)
+        assert np.array_equal(gpu_ctx.merkle4_path_batch(tag, leaves, sib, pos), exp)
+        if depth:
+            d_l = torch.from_numpy(leaves.view(np.int64)).cuda()
+            d_s = torch.from_numpy(sib.view(np.int64)).cuda()
+            d_p = torch.from_numpy(pos).cuda()
+            d_r = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+            gpu_ctx.merkle4_path_batch_device(tag, d_l, d_s, d_p, depth, d_r, n)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_r.cpu().numpy().view(np.uint64), exp)
+    with pytest.raises(ValueError):
+        gpu_ctx.merkle4_path_batch(tag, leaves[:1], np.zeros((1, 1, 3, 4), dtype=np.uint64), np.array([[7]], dtype=np.uint8))
