@@ -85,6 +85,13 @@ int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leav
                       uint64_t root[4], uint64_t* levels);
 size_t p252_merkle4_levels_len(size_t n_leaves);
 
+/* Page-locked host memory (hipHostMalloc).  The host-buffer entry points pipeline H2D / kernel / D2H
+ * over 3 streams for large batches; with buffers from p252_host_alloc the copies run at PCIe speed,
+ * with ordinary (pageable) memory the buffers are page-locked for the duration of each call.  NULL on
+ * failure. */
+void* p252_host_alloc(size_t bytes);
+void p252_host_free(void* p);
+
 /* ---- batched compute, DEVICE buffers (asynchronous on `hip_stream`, a hipStream_t; NULL = the
  * default stream).  Pointers are device addresses with the same layouts as above.  This is the
  * path bench.py times: inputs already resident in HBM. ---- */

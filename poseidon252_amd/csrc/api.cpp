@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -28,6 +29,7 @@ struct p252_ctx {
     size_t d_out_cap = 0;
     void* d_lvl[2] = {nullptr, nullptr};
     size_t d_lvl_cap[2] = {0, 0};
+    hipStream_t streams[3] = {nullptr, nullptr, nullptr};  // host-buffer pipeline (created on first use)
     std::string err;
 };
 
@@ -120,6 +122,8 @@ void p252_destroy(p252_ctx* ctx) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     for (int i = 0; i < 2; ++i)
         if (ctx->d_lvl[i]) (void)hipFree(ctx->d_lvl[i]);
+    for (int i = 0; i < 3; ++i)
+        if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
     delete ctx;
 }
 
@@ -241,10 +245,65 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
     if (rc) return rc;
     rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice));
-    rc = p252_hash_batch_device(ctx, tag, ctx->d_in, in_len, out_len, ctx->d_out, n, nullptr);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost));
+    // Large batches are pipelined: chunks round-robin over 3 streams so that the H2D copy of chunk c+1,
+    // the kernel of chunk c and the D2H copy of chunk c-1 overlap (the call stays synchronous).
+    // P252_HOST_PIPELINE: 0 = serial copies, 1 = pipelined from pageable memory, 2 (default) = pipelined
+    // with the caller's buffers page-locked (hipHostRegister) for the duration of the call.
+    static const int mode = [] {
+        const char* e = std::getenv("P252_HOST_PIPELINE");
+        return e ? std::atoi(e) : 2;
+    }();
+    const size_t chunk_bytes_target = (size_t)16 << 20;
+    size_t chunk = chunk_bytes_target / (in_len * 32);
+    if (chunk < 4096) chunk = 4096;
+    chunk &= ~(size_t)255;
+    if (mode == 0 || n < 2 * chunk) {
+        HIP_TRY(ctx, hipMemcpy(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice));
+        rc = p252_hash_batch_device(ctx, tag, ctx->d_in, in_len, out_len, ctx->d_out, n, nullptr);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost));
+        return P252_OK;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (!ctx->streams[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking));
+    bool reg_in = false, reg_out = false;
+    if (mode == 2) {
+        auto pinned = [](const void* p) {
+            hipPointerAttribute_t a;
+            const bool is = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+            (void)hipGetLastError();
+            return is;
+        };
+        // buffers from p252_host_alloc are already page-locked; anything else is pinned for this call
+        if (!pinned(in)) reg_in = hipHostRegister(const_cast<uint64_t*>(in), in_bytes, hipHostRegisterDefault) == hipSuccess;
+        if (!pinned(out)) reg_out = hipHostRegister(out, out_bytes, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();  // registration is an optimisation: a failure only means slower copies
+    }
+    int status = P252_OK;
+    std::string err;
+    size_t c = 0;
+    for (size_t off = 0; off < n && status == P252_OK; off += chunk, ++c) {
+        const size_t cnt = n - off < chunk ? n - off : chunk;
+        hipStream_t st = ctx->streams[c % 3];
+        const char* h_in = reinterpret_cast<const char*>(in) + off * in_len * 32;
+        char* h_out = reinterpret_cast<char*>(out) + off * out_len * 32;
+        char* d_in = static_cast<char*>(ctx->d_in) + off * in_len * 32;
+        char* d_out = static_cast<char*>(ctx->d_out) + off * out_len * 32;
+        hipError_t e = hipMemcpyAsync(d_in, h_in, cnt * in_len * 32, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            int r2 = p252_hash_batch_device(ctx, tag, d_in, in_len, out_len, d_out, cnt, st);
+            if (r2) { status = r2; err = ctx->err; break; }
+            e = hipMemcpyAsync(h_out, d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, st);
+        }
+        if (e != hipSuccess) { status = P252_ERR_HIP; err = std::string("pipelined copy: ") + hipGetErrorString(e); }
+    }
+    for (int i = 0; i < 3; ++i) {
+        hipError_t e = hipStreamSynchronize(ctx->streams[i]);
+        if (e != hipSuccess && status == P252_OK) { status = P252_ERR_HIP; err = std::string("stream sync: ") + hipGetErrorString(e); }
+    }
+    if (reg_in) (void)hipHostUnregister(const_cast<uint64_t*>(in));
+    if (reg_out) (void)hipHostUnregister(out);
+    if (status != P252_OK) return fail(ctx, status, err);
     return P252_OK;
 }
 
@@ -268,6 +327,20 @@ int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leav
     HIP_TRY(ctx, hipMemcpy(root, d_root, 32, hipMemcpyDeviceToHost));
     if (levels) HIP_TRY(ctx, hipMemcpy(levels, d_levels, lvl_bytes, hipMemcpyDeviceToHost));
     return P252_OK;
+}
+
+// page-locked host memory for callers that want the host-buffer entry points at PCIe speed
+void* p252_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void p252_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 // ------------------------------------------------------------------------------------------

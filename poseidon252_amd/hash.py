@@ -151,13 +151,17 @@ class Context:
         self._check(_lib.lib().p252_permute_batch(self._h, s.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p), s.shape[0]))
         return out
 
-    def hash_batch(self, tag, messages, in_len, out_len):
+    def hash_batch(self, tag, messages, in_len, out_len, out=None):
         tag = _as_scalars(tag).reshape(4)
         m = _as_scalars(messages)
         if in_len <= 0:
             self._check(_lib.ERR_INVALID_IO_PATTERN)
         m = m.reshape(-1, in_len, 4)
-        out = np.empty((m.shape[0], max(out_len, 0), 4), dtype=np.uint64)
+        if out is None:
+            out = np.empty((m.shape[0], max(out_len, 0), 4), dtype=np.uint64)
+        else:  # caller-provided (e.g. pinned) output buffer
+            assert out.dtype == np.uint64 and out.flags.c_contiguous and out.size == m.shape[0] * out_len * 4
+            out = out.reshape(m.shape[0], out_len, 4)
         self._check(_lib.lib().p252_hash_batch(self._h, tag.ctypes.data_as(_u64p), m.ctypes.data_as(_u64p),
                                                 in_len, out_len, out.ctypes.data_as(_u64p), m.shape[0]))
         return out
@@ -245,6 +249,31 @@ class Context:
     def tables_import(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.int32)
         self._check(_lib.lib().p252_tables_import(self._h, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+
+
+class PinnedScalars:
+    """n_scalars BlsScalars in page-locked host memory (p252_host_alloc); `.array` is a numpy view
+    (n_scalars, 4) uint64.  Host-buffer entry points fed from/into such buffers copy at PCIe speed."""
+
+    def __init__(self, n_scalars):
+        nbytes = max(1, int(n_scalars)) * 32
+        self._ptr = _lib.lib().p252_host_alloc(nbytes)
+        if not self._ptr:
+            raise MemoryError("p252_host_alloc(%d) failed" % nbytes)
+        buf = (ctypes.c_uint64 * (nbytes // 8)).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)[:n_scalars]
+
+    def free(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            _lib.lib().p252_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def truncate250(scalars):
