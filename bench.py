@@ -206,7 +206,21 @@ def main():
         step = lambda: ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
     elif wl == "tree":
         d_out = torch.empty(4, dtype=torch.int64, device=dev)
-        step = lambda: ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
+        if world == 1:
+            step = lambda: ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
+        else:
+            # BASELINE configs[4] structure: every rank reduces its complete subtree, the W roots (32 B each)
+            # are all-gathered (the path's only exchange step) and the top levels are hashed on every rank
+            d_roots = torch.empty(world * 4, dtype=torch.int64, device=coll_dev)  # flat: gloo and nccl both accept it
+            d_top = torch.empty(4, dtype=torch.int64, device=dev)
+
+            def step():
+                ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
+                dist.all_gather_into_tensor(d_roots, d_out if coll_dev == dev else d_out.cpu())
+                roots_dev = d_roots if coll_dev == dev else d_roots.to(dev)
+                ctx.merkle4_tree_device(tag, roots_dev.contiguous(), world, d_top, None)
+            perms_per_step += P.levels_len(world)
+            name += " + all-gather of %d subtree roots and top levels" % world
         step()  # allocate the context-owned level scratch outside the timed region
     else:
         d_out = torch.empty((n, 5, 4), dtype=torch.int64, device=dev)

@@ -43,6 +43,19 @@ def test_bench_single_gpu_json_line(gpu_ctx):
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["hbm"]["frac"] < 0.05
 
 
+def test_bench_tree_two_ranks_gather_roots(gpu_ctx):
+    """configs[4] structure at small scale: per-rank subtree, all-gather of the roots, top levels"""
+    env = dict(os.environ, P252_BENCH_SHARE_GPU="1", P252_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--workload", "tree", "--log2n", "12"]
+    out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.DEVNULL)
+    d = _one_json_line(out)
+    assert d["n_gpus"] == 2 and d["parity_sample_ok"] is True
+    assert "all-gather of 2 subtree roots" in d["config"]["workload"]
+    assert d["config"]["units_per_gpu_per_step"] == 1365 + 1  # 4^6 leaves -> 1365 nodes, + 1 top node over 2 roots
+
+
 def test_bench_two_ranks_share_gpu_gloo(gpu_ctx):
     env = dict(os.environ, P252_BENCH_SHARE_GPU="1", P252_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
