@@ -164,8 +164,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get("P252_BENCH_FORCE_DIST") == "1"  # test-only: init the process group at N=1 too
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -227,7 +231,7 @@ def main():
         step = lambda: ctx.hash_batch_device(tag, d_in, 42, 5, d_out, n)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -243,7 +247,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -301,7 +305,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tag)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,7 +33,7 @@ def broadcast_tables(ctx, device=None):
     t = torch.from_numpy(local.copy())
     if device is not None:
         t = t.to(device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.broadcast(t, src=0)
     got = t.cpu().numpy()
     same = bool(np.array_equal(got, local))

@@ -43,6 +43,19 @@ def test_bench_single_gpu_json_line(gpu_ctx):
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["hbm"]["frac"] < 0.05
 
 
+def test_bench_rccl_backend_single_rank(gpu_ctx):
+    """the real nccl (= RCCL) process group on the GPU: init, table broadcast, barrier, all-reduce —
+    one rank is all a 1-GPU box allows, but it is the same code path the 8-GPU run takes"""
+    env = dict(os.environ, P252_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                                   "--log2n", "14", "--no-cpu-baseline"], cwd=ROOT, env=env, timeout=600,
+                                  stderr=subprocess.DEVNULL)
+    d = _one_json_line(out)
+    assert d["n_gpus"] == 1 and d["parity_sample_ok"] is True
+    assert "identical to local derivation: True" in d["config"]["constants"]
+
+
 def test_bench_tree_two_ranks_gather_roots(gpu_ctx):
     """configs[4] structure at small scale: per-rank subtree, all-gather of the roots, top levels"""
     env = dict(os.environ, P252_BENCH_SHARE_GPU="1", P252_BENCH_BACKEND="gloo")
