@@ -1,0 +1,216 @@
+// poseidon252.hpp — C++17 host-side mirror of dusk_poseidon::{Domain, Hash} over the C ABI
+// (include/poseidon252_hip.h).  Header-only; link with -lposeidon252_hip.
+//
+// The reference (dusk-poseidon 0.42, Rust) is compiled code and no Rust toolchain exists in the build
+// image, so the host side above the C ABI is provided in C++ (and in Python, poseidon252_amd/hash.py)
+// with the reference's names, argument meaning and error behaviour:
+//
+//   reference (src/hash.rs)                       here
+//   ------------------------------------------    -----------------------------------------------
+//   enum Domain {Merkle4,Merkle2,Encryption,Other}  enum class Domain            (hash.rs:21-36)
+//   impl From<Domain> for u64                       domain_separator(Domain)     (hash.rs:38-56)
+//   Hash::new / output_len / update / finalize      Hash(...) / same names       (hash.rs:98-155)
+//   Hash::finalize_truncated / digest[_truncated]   same names                   (hash.rs:164-210)
+//   panic!("io-pattern should be valid")            throws IoPatternError        (hash.rs:124-137)
+//   —                                               HashBatch: n messages, one kernel launch
+//
+// A BlsScalar is 4 little-endian u64 Montgomery limbs (a * 2^256 mod p), exactly the reference's
+// memory layout, so buffers are interchangeable with a Rust &[BlsScalar].
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "poseidon252_hip.h"
+
+namespace dusk_poseidon_hip {
+
+using BlsScalar = std::array<uint64_t, 4>;     // Montgomery limbs, as dusk_bls12_381::BlsScalar
+using JubJubRaw = std::array<uint64_t, 4>;     // argument of JubJubScalar::from_raw (hash.rs:180)
+constexpr std::size_t HADES_WIDTH = P252_HADES_WIDTH;  // src/lib.rs:17
+
+enum class Domain : int {  // declaration order of src/hash.rs:21-36
+    Merkle4 = P252_DOMAIN_MERKLE4,
+    Merkle2 = P252_DOMAIN_MERKLE2,
+    Encryption = P252_DOMAIN_ENCRYPTION,
+    Other = P252_DOMAIN_OTHER,
+};
+
+// dusk_poseidon::Error (src/error.rs:9-29) — the variants the hash path can produce.  Where the
+// reference panics (`.expect`, hash.rs:131-154) this mirror throws.
+struct IoPatternError : std::logic_error {
+    enum Kind { IOPatternViolation, InvalidIOPattern } kind;
+    IoPatternError(Kind k, const std::string& what) : std::logic_error(what), kind(k) {}
+};
+struct DeviceError : std::runtime_error {  // no HIP device / HIP failure: there is no CPU fallback
+    using std::runtime_error::runtime_error;
+};
+
+inline uint64_t domain_separator(Domain d) {  // From<Domain> for u64
+    uint64_t sep = 0;
+    p252_domain_separator(static_cast<int>(d), &sep);
+    return sep;
+}
+
+namespace detail {
+inline void check(int rc, p252_ctx* ctx, const char* what) {
+    if (rc == P252_OK) return;
+    const std::string msg = std::string(what) + ": " + (ctx ? p252_last_error(ctx) : "");
+    if (rc == P252_ERR_IO_PATTERN_VIOLATION)
+        throw IoPatternError(IoPatternError::IOPatternViolation, "io-pattern should be valid: IOPatternViolation " + msg);
+    if (rc == P252_ERR_INVALID_IO_PATTERN)
+        throw IoPatternError(IoPatternError::InvalidIOPattern, "at this point the io-pattern is valid: InvalidIOPattern " + msg);
+    if (rc == P252_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    throw DeviceError(msg + " (rc " + std::to_string(rc) + ")");
+}
+}  // namespace detail
+
+// One p252_ctx, bound to one HIP device (one process/thread per GPU).
+class Context {
+  public:
+    explicit Context(int device = 0) {
+        p252_ctx* c = nullptr;
+        const int rc = p252_create(device, &c);
+        if (rc != P252_OK) throw DeviceError(std::string("p252_create: ") + p252_last_error(nullptr));
+        ctx_.reset(c, p252_destroy);
+    }
+    p252_ctx* get() const { return ctx_.get(); }
+    static Context& default_context() {
+        static Context c(0);
+        return c;
+    }
+
+  private:
+    std::shared_ptr<p252_ctx> ctx_;
+};
+
+// io_pattern() of src/hash.rs:62-85 plus dusk-safe's validation; throws like Hash::finalize panics
+inline void check_io_pattern(Domain d, const std::vector<std::size_t>& absorb_lens, std::size_t output_len) {
+    detail::check(p252_check_io_pattern(static_cast<int>(d), absorb_lens.data(), absorb_lens.size(), output_len), nullptr,
+                  "io_pattern");
+}
+
+// Safe::tag for this io-pattern (scalar.rs:29-31).  UNPINNED recipe: pass the value
+// from the real crates through the `tag` parameters instead when it is available.
+inline BlsScalar compute_tag(Domain d, const std::vector<std::size_t>& absorb_lens, std::size_t output_len) {
+    BlsScalar t{};
+    detail::check(p252_tag(static_cast<int>(d), absorb_lens.data(), absorb_lens.size(), output_len, t.data()), nullptr, "tag");
+    return t;
+}
+
+// ---- Hash: one message, absorbed in chunks, squeezed once (src/hash.rs:87-211) ----
+class Hash {
+  public:
+    explicit Hash(Domain domain, Context& ctx = Context::default_context()) : domain_(domain), ctx_(ctx) {}  // Hash::new
+    static Hash new_(Domain domain) { return Hash(domain); }
+
+    // hash.rs:111-115: honoured only for Domain::Other and output_len > 0
+    void output_len(std::size_t n) {
+        if (domain_ == Domain::Other && n > 0) output_len_ = n;
+    }
+    // hash.rs:118-120: the slice is borrowed, never copied or modified; it must outlive finalize()
+    void update(const BlsScalar* input, std::size_t len) { input_.emplace_back(input, len); }
+    void update(const std::vector<BlsScalar>& input) { update(input.data(), input.size()); }
+
+    // hash.rs:128-155.  Throws IoPatternError where the reference panics.
+    std::vector<BlsScalar> finalize() const {
+        std::vector<std::size_t> lens;
+        std::size_t total = 0;
+        for (auto& c : input_) {
+            lens.push_back(c.second);
+            total += c.second;
+        }
+        check_io_pattern(domain_, lens, output_len_);
+        const BlsScalar tag = has_tag_ ? tag_ : compute_tag(domain_, lens, output_len_);
+        std::vector<BlsScalar> msg;
+        msg.reserve(total);
+        for (auto& c : input_) msg.insert(msg.end(), c.first, c.first + c.second);
+        std::vector<BlsScalar> out(output_len_);
+        detail::check(p252_hash_batch(ctx_.get(), tag.data(), msg[0].data(), total, output_len_, out[0].data(), 1), ctx_.get(),
+                      "Hash::finalize");
+        return out;
+    }
+    // hash.rs:164-183
+    std::vector<JubJubRaw> finalize_truncated() const {
+        const std::vector<BlsScalar> bls = finalize();
+        std::vector<JubJubRaw> out(bls.size());
+        detail::check(p252_truncate250(bls[0].data(), out[0].data(), bls.size()), nullptr, "truncate");
+        return out;
+    }
+    // hash.rs:191-195, 203-210
+    static std::vector<BlsScalar> digest(Domain domain, const std::vector<BlsScalar>& input) {
+        Hash h(domain);
+        h.update(input);
+        return h.finalize();
+    }
+    static std::vector<JubJubRaw> digest_truncated(Domain domain, const std::vector<BlsScalar>& input) {
+        Hash h(domain);
+        h.update(input);
+        return h.finalize_truncated();
+    }
+    // inject the capacity element computed by the real crates (BlsScalar::hash_to_scalar)
+    void set_tag(const BlsScalar& tag) {
+        tag_ = tag;
+        has_tag_ = true;
+    }
+
+  private:
+    Domain domain_;
+    Context& ctx_;
+    std::vector<std::pair<const BlsScalar*, std::size_t>> input_;
+    std::size_t output_len_ = 1;
+    BlsScalar tag_{};
+    bool has_tag_ = false;
+};
+
+// ---- HashBatch: n independent messages with one io-pattern in one kernel launch.  Per item the
+// result equals Hash::digest(domain, item): same validation, same tag, same output order. ----
+class HashBatch {
+  public:
+    HashBatch(Domain domain, std::size_t item_len, std::size_t output_len = 1, Context& ctx = Context::default_context())
+        : domain_(domain), item_len_(item_len), output_len_((domain == Domain::Other && output_len > 0) ? output_len : 1), ctx_(ctx) {
+        check_io_pattern(domain_, {item_len_}, output_len_);
+        tag_ = compute_tag(domain_, {item_len_}, output_len_);
+    }
+    void set_tag(const BlsScalar& tag) { tag_ = tag; }
+    const BlsScalar& tag() const { return tag_; }
+    std::size_t output_len() const { return output_len_; }
+
+    // host buffers: input.size() must be a multiple of item_len
+    std::vector<BlsScalar> digest(const std::vector<BlsScalar>& input) const {
+        if (item_len_ == 0 || input.size() % item_len_) throw std::invalid_argument("HashBatch::digest: ragged input");
+        const std::size_t n = input.size() / item_len_;
+        std::vector<BlsScalar> out(n * output_len_);
+        if (n)
+            detail::check(p252_hash_batch(ctx_.get(), tag_.data(), input[0].data(), item_len_, output_len_, out[0].data(), n),
+                          ctx_.get(), "HashBatch::digest");
+        return out;
+    }
+    // device buffers, asynchronous on `stream` (a hipStream_t)
+    void digest_device(const void* d_in, void* d_out, std::size_t n, void* stream = nullptr) const {
+        detail::check(p252_hash_batch_device(ctx_.get(), tag_.data(), d_in, item_len_, output_len_, d_out, n, stream), ctx_.get(),
+                      "HashBatch::digest_device");
+    }
+
+  private:
+    Domain domain_;
+    std::size_t item_len_, output_len_;
+    Context& ctx_;
+    BlsScalar tag_{};
+};
+
+// Arity-4 Merkle root over Hash::digest(Domain::Merkle4, ..) nodes (empty slots = zero, hash.rs:22-26)
+inline BlsScalar merkle4_root(const std::vector<BlsScalar>& leaves, Context& ctx = Context::default_context()) {
+    const BlsScalar tag = compute_tag(Domain::Merkle4, {4}, 1);
+    BlsScalar root{};
+    if (leaves.empty()) throw std::invalid_argument("merkle4_root: no leaves");
+    detail::check(p252_merkle4_tree(ctx.get(), tag.data(), leaves[0].data(), leaves.size(), root.data(), nullptr), ctx.get(),
+                  "merkle4_root");
+    return root;
+}
+
+}  // namespace dusk_poseidon_hip

@@ -1,0 +1,155 @@
+// C++ host-side tests of include/poseidon252.hpp on the GPU, written to read like the reference's own
+// tests: README.md:22-51 (doctest), tests/hash.rs:101-116,188-203,277-292 (input shapes 3/5/15,
+// truncated, multi-output (3,3) (5,2) (4,7)), src/hades.rs:94-162 (known-answer test, through the HIP
+// sponge with tag = 0), src/hash.rs:124-137 (panics -> exceptions).  The oracle (oracle/p252_oracle.h)
+// is linked as the checker only.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "poseidon252.hpp"
+#include "../../oracle/p252_oracle.h"
+
+using namespace dusk_poseidon_hip;
+
+static int failures = 0;
+#define EXPECT(cond)                                                        \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);     \
+            ++failures;                                                     \
+        }                                                                   \
+    } while (0)
+
+static std::vector<BlsScalar> random_scalars(uint64_t seed, size_t n) {
+    std::vector<BlsScalar> v(n);
+    p252o_fill_random(seed, v[0].data(), n);
+    return v;
+}
+
+static std::vector<BlsScalar> oracle_hash(const BlsScalar& tag, const std::vector<BlsScalar>& in, size_t in_len, size_t out_len) {
+    const size_t n = in.size() / in_len;
+    std::vector<BlsScalar> out(n * out_len);
+    p252o_hash_batch(tag.data(), in[0].data(), in_len, out_len, out[0].data(), n);
+    return out;
+}
+
+template <class F>
+static bool throws_io(F f, IoPatternError::Kind kind) {
+    try {
+        f();
+    } catch (const IoPatternError& e) {
+        return e.kind == kind;
+    } catch (...) {
+    }
+    return false;
+}
+
+int main() {
+    // ---- README.md:31-51 ----
+    {
+        auto input = random_scalars(0xbeef, 42);
+        auto hash = Hash::new_(Domain::Other);
+        hash.update(input.data(), 3);
+        hash.update(input.data() + 3, 39);
+        EXPECT(hash.finalize() == Hash::digest(Domain::Other, input));  // chunked update == one-shot digest
+        std::vector<BlsScalar> four(input.begin(), input.begin() + 4);
+        EXPECT(Hash::digest(Domain::Merkle4, four) != Hash::digest(Domain::Other, four));
+    }
+    // ---- tests/hash.rs shapes against the oracle ----
+    for (size_t n_in : {3, 5, 15}) {
+        auto input = random_scalars(0xbeef + n_in, n_in);
+        auto got = Hash::digest(Domain::Other, input);
+        EXPECT(got.size() == 1);
+        EXPECT(got == oracle_hash(compute_tag(Domain::Other, {n_in}, 1), input, n_in, 1));
+    }
+    for (auto io : {std::pair<size_t, size_t>{3, 3}, {5, 2}, {4, 7}}) {
+        auto input = random_scalars(0xbeef + 16 * io.first + io.second, io.first);
+        Hash h(Domain::Other);
+        h.output_len(io.second);
+        h.update(input);
+        auto got = h.finalize();
+        EXPECT(got.size() == io.second);
+        EXPECT(got == oracle_hash(compute_tag(Domain::Other, {io.first}, io.second), input, io.first, io.second));
+    }
+    {  // truncated (hash.rs:164-183)
+        auto input = random_scalars(0xbeef + 5, 5);
+        auto t = Hash::digest_truncated(Domain::Other, input);
+        auto full = Hash::digest(Domain::Other, input);
+        JubJubRaw exp;
+        p252o_truncate250(full[0].data(), exp.data());
+        EXPECT(t.size() == 1 && t[0] == exp && (t[0][3] >> 58) == 0);
+    }
+    // ---- output_len rules (hash.rs:111-115) and panics (hash.rs:124-137) ----
+    {
+        auto input = random_scalars(1, 8);
+        Hash m4(Domain::Merkle4);
+        m4.output_len(3);  // ignored for Merkle4
+        m4.update(input.data(), 4);
+        EXPECT(m4.finalize().size() == 1);
+        EXPECT(throws_io([&] { Hash h(Domain::Merkle4); h.update(input.data(), 3); h.finalize(); }, IoPatternError::IOPatternViolation));
+        EXPECT(throws_io([&] { Hash h(Domain::Merkle2); h.update(input.data(), 4); h.finalize(); }, IoPatternError::IOPatternViolation));
+        EXPECT(throws_io([&] { Hash h(Domain::Other); h.finalize(); }, IoPatternError::InvalidIOPattern));
+        EXPECT(throws_io([&] { HashBatch hb(Domain::Merkle4, 5); }, IoPatternError::IOPatternViolation));
+        EXPECT(domain_separator(Domain::Merkle4) == 0xf && domain_separator(Domain::Merkle2) == 0x3 &&
+               domain_separator(Domain::Encryption) == 0x100000000ULL && domain_separator(Domain::Other) == 0);
+    }
+    // ---- the reference's known-answer test through the HIP sponge (tag forced to zero) ----
+    {
+        static const char* INPUTS[10] = {
+            "bb67ed265bf1db490ded2e1ede55c0d14c55521509dc73f9c354e98ab76c9625", "7e74220084d75e10c89e9435d47bb5b8075991b2e29be3b84421dac3b1ee6007",
+            "5ce5481a4d78cca03498f72761da1b9f1d2aa8fb300be39f0e4fe2534f9d4308", "b1e710e3c4a8c35154b0ce4e4f4af6f498ebd79f8e7cdf3150372c7501be250b",
+            "33c9e2025f86b5d82149f1ab8e20a168fc3d99d09b48cbce0286db8752cc3306", "e98206bfdce791e4e5144079b997d4fc25006194b35655f0e48490b26e24ea35",
+            "86d2a95cc552de8d5bb20bd4a407fee5ffdc314e93dfe6b2dc792bc71fd8cc2d", "4edd8307ce28a8c70963d20a7bc28df1e1720bbbc93878a18bd07fad7d51fa15",
+            "eabc7a296704a68aa01f95adc85f6dd758b175745336d8fc795a17984024b21e", "cfc108673c93df305e31c283b9c767b7097ae4e174a223e0c24b15a67b701a3a"};
+        struct { size_t n; const char* be_hex; } KAT[6] = {
+            {3, "26abf2d0476f154e69bf19740092fe36265680c294462b8e759ad73a99567dd5"}, {4, "1cc40219c7ec92919d6db7a41cd41953333a2ed544606daca182e4eaa6c7db2d"},
+            {5, "707c98a0e9a6e4832ac33ee08811bce122017a58dbbbf66a2f6fcdc69d45462d"}, {6, "26905a794d3d2fb0c3ed2276abc696c27a5bfdea7f106e596cbeedd86891c461"},
+            {8, "1b98a2c5f1fe54d21b5ce9bf0dcc99ea8784a64f3c544fa06d3f73569741006e"}, {10, "211b7ea21c9afca93dabdfbda8b2d5275b2dd802fed87bb431e98557c61667d2"}};
+        std::vector<BlsScalar> all(11);
+        for (int i = 0; i < 10; ++i) {
+            uint64_t raw[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 32; ++b) {  // from_hex_str: little-endian canonical bytes
+                unsigned byte;
+                std::sscanf(INPUTS[i] + 2 * b, "%2x", &byte);
+                raw[b / 8] |= (uint64_t)byte << (8 * (b % 8));
+            }
+            p252o_from_raw(raw, all[i].data());
+        }
+        const uint64_t one_raw[4] = {1, 0, 0, 0};
+        BlsScalar one;
+        p252o_from_raw(one_raw, one.data());
+        for (auto& k : KAT) {
+            std::vector<BlsScalar> msg(all.begin(), all.begin() + k.n);
+            msg.push_back(one);  // the KAT pads with BlsScalar::one()
+            Hash h(Domain::Other);
+            h.set_tag(BlsScalar{0, 0, 0, 0});
+            h.update(msg);
+            auto out = h.finalize();
+            uint64_t canon[4];
+            p252o_to_canonical(out[0].data(), canon);
+            char hex[65];
+            for (int b = 0; b < 32; ++b) std::snprintf(hex + 2 * b, 3, "%02x", (unsigned)((canon[3 - b / 8] >> (8 * (7 - b % 8))) & 0xff));
+            EXPECT(std::string(hex) == k.be_hex);
+        }
+    }
+    // ---- HashBatch == n x Hash::digest == oracle; Merkle root ----
+    {
+        HashBatch hb(Domain::Merkle4, 4);
+        auto input = random_scalars(0xc10d, 4 * 3000);
+        auto got = hb.digest(input);
+        EXPECT(got == oracle_hash(hb.tag(), input, 4, 1));
+        std::vector<BlsScalar> first(input.begin(), input.begin() + 4);
+        EXPECT(Hash::digest(Domain::Merkle4, first)[0] == got[0]);
+        HashBatch hb5(Domain::Other, 42, 5);
+        auto m = random_scalars(7, 42 * 100);
+        EXPECT(hb5.digest(m) == oracle_hash(hb5.tag(), m, 42, 5));
+        auto leaves = random_scalars(9, 1000);
+        BlsScalar exp_root;
+        p252o_merkle4_tree(hb.tag().data(), leaves[0].data(), leaves.size(), exp_root.data(), nullptr);
+        EXPECT(merkle4_root(leaves) == exp_root);
+    }
+    std::printf(failures ? "C++ HOST API: %d FAILURES\n" : "C++ HOST API: ALL PASSED\n", failures);
+    return failures ? 1 : 0;
+}
