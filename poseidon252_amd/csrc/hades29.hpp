@@ -161,13 +161,13 @@ P252_HD void entry_round(E29 s[WIDTH], E29 h[9], TP tab) {
 // instruction stream.  Phases (step): 0-3 full (3 = entry matrix) | 4-7 entry q=1..4 | 8-63 ARMA
 // q=5..60 | 64 exit | 65-68 full.  OUT_ROWS: bit k set = lane k of the result is needed (a Merkle4
 // digest needs lane 1 only, so the last round computes 1 of its 5 rows).
-template <unsigned OUT_ROWS = 0x1fu, class TP>
+template <unsigned OUT_ROWS = 0x1fu, int ARMA_UNROLL_T = P252_ARMA_UNROLL, class TP>
 P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
     constexpr int N_ENTRY = 4;
     constexpr int STEP_ARMA0 = RF + N_ENTRY;                           // 8
-    constexpr int ARMA_UNROLL = P252_ARMA_UNROLL;  // ARMA rounds per loop step (history shifts become renames)
+    constexpr int ARMA_UNROLL = ARMA_UNROLL_T;  // ARMA rounds per loop step (history shifts become renames)
     static_assert((PARTIAL_ROUNDS - N_ENTRY) % ARMA_UNROLL == 0, "56 ARMA rounds must split evenly");
     constexpr int STEP_EXIT = STEP_ARMA0 + (PARTIAL_ROUNDS - N_ENTRY) / ARMA_UNROLL;
     constexpr int STEP_END = STEP_EXIT + 1 + RF;                       // 69

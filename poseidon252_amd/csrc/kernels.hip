@@ -11,6 +11,19 @@
 #include "hades29.hpp"
 #include "kernels.h"
 
+// ARMA rounds per loop iteration, per kernel.  Measured on MI355X (42->5 sponge, 2^20 messages): unroll 1 / 2 / 4 =
+// 2.71e8 / 2.59e8 / 2.39e8 perm/s (code size and SGPR spills grow); the digest kernel k_merkle4 is the
+// opposite (2.78e8 / 2.79e8 / 2.85e8) and keeps the header default of 4.
+#ifndef P252_UNROLL_PERMUTE
+#define P252_UNROLL_PERMUTE 1
+#endif
+#ifndef P252_UNROLL_SPONGE
+#define P252_UNROLL_SPONGE 1
+#endif
+#ifndef P252_UNROLL_PATH
+#define P252_UNROLL_PATH 1
+#endif
+
 namespace p252 {
 
 struct alignas(16) Scalar32 {
@@ -40,7 +53,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restric
     E29 s[WIDTH];
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) s[k] = load_scalar(in + idx * WIDTH + k);
-    hades_permute(s, tab);
+    hades_permute<0x1fu, P252_UNROLL_PERMUTE>(s, tab);
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) store_scalar(out + idx * WIDTH + k, s[k]);
 }
@@ -91,7 +104,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
         if ((unsigned)k < in_len) s[1 + k] = load_scalar(my_in + k);
 #pragma unroll 1
     for (unsigned it = 1; it < absorb_blocks + squeeze_blocks; ++it) {
-        hades_permute(s, tab);
+        hades_permute<0x1fu, P252_UNROLL_SPONGE>(s, tab);
         if (it < absorb_blocks) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -156,7 +169,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path(const int32_t* __re
             s[3].d[k] = p == 2 ? cur.d[k] : (p < 2 ? b.d[k] : c.d[k]);
             s[4].d[k] = p == 3 ? cur.d[k] : c.d[k];
         }
-        hades_permute<0x02u>(s, tab);
+        hades_permute<0x02u, P252_UNROLL_PATH>(s, tab);
         cur = s[1];
     }
     store_scalar(roots + idx, cur);
