@@ -1,0 +1,103 @@
+"""BASELINE.json configs at FULL size on the GPU, checked through size-independent properties
+(subtree composition, shard consistency, oracle spot checks), plus a randomized-shape sweep."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_full_2pow24_leaf_tree(gpu_ctx, oracle_mod):
+    """2^24-leaf arity-4 tree (512 MiB of leaves, 5,592,405 permutations):
+       root == tree over the 16 roots of the 2^20-leaf subtrees == tree over 1024 roots of 2^14-leaf
+       subtrees; one 2^14-leaf subtree root is recomputed by the oracle."""
+    import torch
+    import poseidon252_amd as P
+    n = 1 << 24
+    tag = oracle_mod.tag(0, [4], 1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(24)
+    d = torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    root = P.merkle4_tree(d, tag=tag, ctx=gpu_ctx)
+    sub20 = torch.stack([P.merkle4_tree(d[i << 20:(i + 1) << 20], tag=tag, ctx=gpu_ctx) for i in range(16)])
+    assert torch.equal(P.merkle4_tree(sub20.contiguous(), tag=tag, ctx=gpu_ctx), root)
+    # level 7 of the global tree = roots of the 1024 subtrees of 4^7 leaves: one batched level-by-level pass
+    lv = d
+    for _ in range(7):
+        nxt = torch.empty((lv.shape[0] // 4, 4), dtype=torch.int64, device="cuda")
+        gpu_ctx.hash_batch_device(tag, lv, 4, 1, nxt, lv.shape[0] // 4)
+        lv = nxt
+    assert torch.equal(P.merkle4_tree(lv.contiguous(), tag=tag, ctx=gpu_ctx), root)
+    torch.cuda.synchronize()
+    k = 777  # subtree index
+    leaves_k = d[k << 14:(k + 1) << 14].cpu().numpy().view(np.uint64)
+    assert np.array_equal(lv[k].cpu().numpy().view(np.uint64), oracle_mod.merkle4_tree(tag, leaves_k)[0])
+    assert P.levels_len(n) == 5592405
+
+
+def test_config2_scaled_up_2pow24_digests(gpu_ctx, oracle_mod):
+    """16 x configs[1]: 2^24 digests in one launch (2 GiB in): grid arithmetic, spot parity, shard consistency"""
+    import torch
+    n = 1 << 24
+    tag = oracle_mod.tag(0, [4], 1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2)
+    d_in = torch.randint(0, 2 ** 62, (n * 4, 4), dtype=torch.int64, device="cuda", generator=g)
+    d_out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
+    idx = torch.tensor([0, 1, 255, 256, n // 2 - 1, n // 2, n - 257, n - 1], device="cuda")
+    sel_in = d_in.view(n, 4, 4)[idx].cpu().numpy().view(np.uint64)
+    assert np.array_equal(d_out[idx].cpu().numpy().view(np.uint64), oracle_mod.hash_batch(tag, sel_in, 4, 1).reshape(-1, 4))
+    lo = (1 << 23) + 12345
+    d_out2 = torch.empty((4096, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx.hash_batch_device(tag, d_in[lo * 4:(lo + 4096) * 4], 4, 1, d_out2, 4096)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out2, d_out[lo:lo + 4096])
+
+
+def test_config4_full_2pow20_sponges(gpu_ctx, oracle_mod):
+    """Domain::Other, 2^20 messages x 42 scalars -> 5 outputs (1.3 GiB in, 12 permutations each)"""
+    import torch
+    import poseidon252_amd as P
+    n = 1 << 20
+    hb = P.HashBatch(P.Domain.Other, 42, output_len=5, ctx=gpu_ctx)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    d_in = torch.randint(0, 2 ** 62, (n * 42, 4), dtype=torch.int64, device="cuda", generator=g)
+    out = hb.digest(d_in)
+    torch.cuda.synchronize()
+    idx = torch.arange(0, n, 8191, device="cuda")
+    sel = d_in.view(n, 42, 4)[idx].cpu().numpy().view(np.uint64)
+    assert np.array_equal(out[idx].cpu().numpy().view(np.uint64), oracle_mod.hash_batch(hb.tag, sel, 42, 5))
+
+
+def test_random_shapes_sweep(gpu_ctx, oracle_mod):
+    """60 random (n, in_len, out_len) triples, ragged batch sizes, random tags"""
+    rng = np.random.default_rng(2026)
+    for case in range(60):
+        n = int(rng.integers(1, 700))
+        in_len = int(rng.integers(1, 23))
+        out_len = int(rng.integers(1, 11))
+        tag = oracle_mod.fill_random(9000 + case, 1)[0]
+        m = oracle_mod.fill_random(10000 + case, n * in_len).reshape(n, in_len, 4)
+        got = gpu_ctx.hash_batch(tag, m, in_len, out_len)
+        assert np.array_equal(got, oracle_mod.hash_batch(tag, m, in_len, out_len)), (n, in_len, out_len)
+
+
+def test_two_contexts_and_streams(gpu_ctx, oracle_mod):
+    """distinct contexts are independent; work on a non-default torch stream is ordered on that stream"""
+    import torch
+    import poseidon252_amd as P
+    ctx2 = P.Context(0)
+    tag = oracle_mod.tag(0, [4], 1)
+    x = oracle_mod.fill_random(77, 4 * 5000).reshape(5000, 4, 4)
+    exp = oracle_mod.hash_batch(tag, x, 4, 1)
+    assert np.array_equal(ctx2.hash_batch(tag, x, 4, 1), exp)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = torch.from_numpy(x.view(np.int64)).cuda(non_blocking=True)
+        out = torch.empty((5000, 4), dtype=torch.int64, device="cuda")
+        ctx2.hash_batch_device(tag, d, 4, 1, out, 5000)
+        gpu_ctx.hash_batch_device(tag, d, 4, 1, out, 5000)  # second context, same stream, same answer
+    s.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64).reshape(5000, 1, 4), exp)
+    ctx2.close()
