@@ -69,6 +69,25 @@ def pmc_traffic(workload, units_per_launch):
             "algorithmic_bytes": 160.0 * units_per_launch, "source": os.path.relpath(path, ROOT)}
 
 
+def pmc_valu(workload):
+    """VALU issue utilisation of the dominant kernel from the committed --pmc pass (SQ_INSTS_VALU,
+    GRBM_GUI_ACTIVE): instructions per SIMD-cycle, where a stream of 4-cycle-class instructions
+    (v_mad_i64_i32, 64-bit adds/shifts) saturates at 0.25."""
+    import glob
+    if workload != "merkle4_digests":
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_merkle4.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            c = d["counters"]
+            per_simd_cycle = c["SQ_INSTS_VALU"] / (1024.0 * d["gpu_cycles_per_launch"])
+            return {"valu_insts_per_permutation": d["valu_insts_per_wave"] / 64.0, "valu_insts_per_simd_cycle": per_simd_cycle,
+                    "saturation_for_4cycle_class": 0.25, "source": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def usable_cpus():
     """threads worth starting: min(affinity mask, cgroup CPU quota) — the GPU box reports 256 logical CPUs
     but a container quota may allow far fewer"""
@@ -285,7 +304,8 @@ def main():
             "metric": "Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact",
             "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 limbs (9x29-bit) / int64 columns", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "dtype_note": "255-bit field elements as 9 x 29-bit limbs (int32), products accumulated in signed 64-bit columns (v_mad_i64_i32)",
             "config": {"workload": name, "units_per_gpu_per_step": perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
                        "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
             "roofline": {
@@ -299,7 +319,11 @@ def main():
                 "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
                         "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
                 "traffic": pmc_traffic(wl, perms_per_step),
+                "valu_issue": pmc_valu(wl),
             },
+            # the same kernel priced against the HBM roofline in the contract's shape (NOT the binding bound here)
+            "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": hbm_gbps / PEAK_HBM_GBPS, "traffic": pmc_traffic(wl, perms_per_step)},
             "parity_sample_ok": checked,
         }
         if world == 1 and not args.no_cpu_baseline:
