@@ -12,8 +12,9 @@ rank 0 broadcasts the constant table over RCCL once, before the timed region.
 
 Prints ONE JSON line (rank 0) with `roofline` (VALU int32-MAC bound — DESIGN.md §3; HBM figures are
 included, the path is not HBM- or MFMA-bound) and, at N=1, `cpu_baseline` (the C oracle, kind "port",
-timed on the host cores on a bounded sample).  The oracle is used here ONLY as the checker of a
-sample of the GPU output and as the CPU baseline; it is never the thing measured as `value`.
+timed on the host cores on a bounded sample).  oracle/ is touched ONLY inside that cpu_baseline leg,
+where it is timed and, as a by-product, checks a sample of the GPU output just measured; every run
+(any N) additionally performs an oracle-free GPU self-consistency check.
 """
 import argparse
 import json
@@ -109,9 +110,11 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(tag):
+def cpu_baseline(tag, gpu_sample=None):
     """The oracle (C restatement of the reference CPU path, reference schedule: 2000 mults/perm) on the
-    host cores.  Bounded sample: 2^14 digests on 1 thread, then 2^14 per thread on all threads."""
+    host cores.  Bounded sample: 2^14 digests on 1 thread, then 2^14 per thread on all threads.
+    gpu_sample = (kind, inputs, in_len, out_len, gpu_output): inputs of the run just timed with the GPU's
+    answers — recomputed here on the CPU and compared (reported as parity_sample_ok)."""
     import oracle
     try:  # rebuild for this host's ISA when a compiler is present (mulx/adx); fall back to the shipped build
         import subprocess
@@ -156,7 +159,13 @@ def cpu_baseline(tag):
                 break
     except OSError:
         pass
-    return {"value": nall / best, "unit": "permutations/s", "cores": threads, "kind": "port",
+    parity = None
+    if gpu_sample is not None:
+        kind, inp, in_len, out_len, got = gpu_sample
+        exp = oracle.merkle4_tree(tag, inp)[0] if kind == "tree" else oracle.hash_batch(tag, inp, in_len, out_len)
+        parity = bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(exp).reshape(-1)))
+    return {"parity_sample_ok": parity,
+            "value": nall / best, "unit": "permutations/s", "cores": threads, "kind": "port",
             "sample": "Hash::digest(Merkle4, 4 scalars): %d digests on %d threads (best of 3); 1 thread: %d digests"
                       % (nall, threads, n1),
             "value_1core": n1 / t1, "cpu": cpu_model, "compiler": "gcc " + flags,
@@ -271,26 +280,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # correctness of what was just timed: a strided sample of this rank's output against the oracle
-    checked = None
-    if not args.no_check and rank == 0:
-        import oracle
-        h_in = d_in.cpu().numpy().view(np.uint64)
+    # correctness of what was just timed, WITHOUT the oracle (every rank, every N): a slice of the batch is
+    # hashed again on its own and must reproduce the same digests (shard consistency + determinism)
+    self_ok = None
+    if not args.no_check:
         if wl == "merkle4_digests":
-            idx = np.arange(0, n, max(1, n // 512))
-            exp = oracle.hash_batch(tag, h_in.reshape(n, 4, 4)[idx], 4, 1).reshape(-1, 4)
-            got = d_out.cpu().numpy().view(np.uint64)[idx]
+            lo, cnt = n // 3, min(n - n // 3, 4096)
+            again = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
+            ctx.hash_batch_device(tag, d_in[lo * 4:(lo + cnt) * 4], 4, 1, again, cnt)
+            torch.cuda.synchronize()
+            self_ok = bool(torch.equal(again, d_out[lo:lo + cnt]))
         elif wl == "tree":
-            sub = 1 << 12  # the root over the first 4^6 leaves, recomputed on the GPU and on the oracle
-            exp = oracle.merkle4_tree(tag, h_in[:sub])[0]
-            got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
+            # subtree composition: the tree over the 4 quarter-tree roots is the tree's root
+            quarters = torch.stack([P.merkle4_tree(d_in[i * (n // 4):(i + 1) * (n // 4)], tag=tag, ctx=ctx) for i in range(4)])
+            top = P.merkle4_tree(quarters.contiguous(), tag=tag, ctx=ctx)
+            ref = torch.empty(4, dtype=torch.int64, device=dev)
+            ctx.merkle4_tree_device(tag, d_in, n, ref, None)
+            torch.cuda.synchronize()
+            self_ok = bool(torch.equal(top, ref))
         else:
-            idx = np.arange(0, n, max(1, n // 128))
-            exp = oracle.hash_batch(tag, h_in.reshape(n, 42, 4)[idx], 42, 5)
-            got = d_out.cpu().numpy().view(np.uint64).reshape(n, 5, 4)[idx]
-        checked = bool(np.array_equal(got, exp))
-        if not checked:
-            print("PARITY FAILURE: GPU output differs from the oracle", file=sys.stderr)
+            lo, cnt = n // 3, min(n - n // 3, 1024)
+            again = torch.empty((cnt, 5, 4), dtype=torch.int64, device=dev)
+            ctx.hash_batch_device(tag, d_in[lo * 42:(lo + cnt) * 42], 42, 5, again, cnt)
+            torch.cuda.synchronize()
+            self_ok = bool(torch.equal(again, d_out[lo:lo + cnt]))
+        if not self_ok:
+            print("SELF-CONSISTENCY FAILURE on rank %d" % rank, file=sys.stderr)
             sys.exit(3)
 
     if rank == 0:
@@ -324,10 +339,28 @@ def main():
             # the same kernel priced against the HBM roofline in the contract's shape (NOT the binding bound here)
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": hbm_gbps / PEAK_HBM_GBPS, "traffic": pmc_traffic(wl, perms_per_step)},
-            "parity_sample_ok": checked,
+            "self_consistency_ok": self_ok,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(tag)
+            # the cpu_baseline leg is the ONLY place bench.py touches oracle/: it times the CPU restatement and,
+            # as a by-product, checks a strided sample of the GPU output just measured against it
+            sample = None
+            if not args.no_check:
+                h_in = d_in.cpu().numpy().view(np.uint64)
+                if wl == "merkle4_digests":
+                    idx = np.arange(0, n, max(1, n // 512))
+                    sample = ("hash", h_in.reshape(n, 4, 4)[idx], 4, 1, d_out.cpu().numpy().view(np.uint64)[idx].reshape(-1, 1, 4))
+                elif wl == "tree":
+                    sub = 1 << 12
+                    got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
+                    sample = ("tree", h_in[:sub], None, None, got)
+                else:
+                    idx = np.arange(0, n, max(1, n // 128))
+                    sample = ("hash", h_in.reshape(n, 42, 4)[idx], 42, 5, d_out.cpu().numpy().view(np.uint64).reshape(n, 5, 4)[idx])
+            line["cpu_baseline"] = cpu_baseline(tag, sample)
+            if line["cpu_baseline"].get("parity_sample_ok") is False:
+                print("PARITY FAILURE: GPU output differs from the oracle", file=sys.stderr)
+                sys.exit(3)
         print(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()

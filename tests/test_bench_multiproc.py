@@ -37,10 +37,21 @@ def test_bench_single_gpu_json_line(gpu_ctx):
     d = _one_json_line(out)
     for k in REQUIRED:
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["parity_sample_ok"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["self_consistency_ok"] is True
     assert d["value"] > 1e6 and d["scaling"] == "weak" and d["vs_baseline"] is None
     r = d["roofline"]
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["hbm"]["frac"] < 0.05
+
+
+def test_bench_cpu_baseline_leg_checks_gpu_sample(gpu_ctx):
+    """default-shaped run at N=1 (small batch): the cpu_baseline leg times the oracle and verifies a
+    sample of the GPU output that was just measured"""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                                   "--log2n", "14"], cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
+    d = _one_json_line(out)
+    cb = d["cpu_baseline"]
+    assert cb["parity_sample_ok"] is True and cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e3
+    assert d["self_consistency_ok"] is True
 
 
 def test_bench_rccl_backend_single_rank(gpu_ctx):
@@ -52,7 +63,7 @@ def test_bench_rccl_backend_single_rank(gpu_ctx):
                                    "--log2n", "14", "--no-cpu-baseline"], cwd=ROOT, env=env, timeout=600,
                                   stderr=subprocess.DEVNULL)
     d = _one_json_line(out)
-    assert d["n_gpus"] == 1 and d["parity_sample_ok"] is True
+    assert d["n_gpus"] == 1 and d["self_consistency_ok"] is True
     assert "identical to local derivation: True" in d["config"]["constants"]
 
 
@@ -64,7 +75,7 @@ def test_bench_tree_two_ranks_gather_roots(gpu_ctx):
            "--warmup", "1", "--workload", "tree", "--log2n", "12"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.DEVNULL)
     d = _one_json_line(out)
-    assert d["n_gpus"] == 2 and d["parity_sample_ok"] is True
+    assert d["n_gpus"] == 2 and d["self_consistency_ok"] is True
     assert "all-gather of 2 subtree roots" in d["config"]["workload"]
     assert d["config"]["units_per_gpu_per_step"] == 1365 + 1  # 4^6 leaves -> 1365 nodes, + 1 top node over 2 roots
 
@@ -76,7 +87,7 @@ def test_bench_two_ranks_share_gpu_gloo(gpu_ctx):
            "--warmup", "1", "--log2n", "16"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.DEVNULL)
     d = _one_json_line(out)
-    assert d["n_gpus"] == 2 and d["parity_sample_ok"] is True and "cpu_baseline" not in d
+    assert d["n_gpus"] == 2 and d["self_consistency_ok"] is True and "cpu_baseline" not in d
     assert "identical to local derivation: True" in d["config"]["constants"]
     # whole-job value = 2 ranks x units / max-over-ranks time
     assert d["value"] == pytest.approx(2 * d["config"]["units_per_gpu_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
