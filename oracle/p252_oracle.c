@@ -62,32 +62,38 @@ static inline void fr_add(fr_t *o, const fr_t *a, const fr_t *b) {
 }
 
 /* BlsScalar * BlsScalar: 4x4 schoolbook to 512 bits, Montgomery reduction, conditional subtract */
+#define MAC(lo, hi, a, b, c, d)                         \
+    do {                                                \
+        u128 r_ = (u128)(a) * (b) + (c) + (d);          \
+        (lo) = (uint64_t)r_;                            \
+        (hi) = (uint64_t)(r_ >> 64);                    \
+    } while (0)
 static inline void fr_mul(fr_t *o, const fr_t *a, const fr_t *b) {
-    uint64_t t[8] = {0};
-    for (int i = 0; i < 4; ++i) {
-        u128 c = 0;
-        for (int j = 0; j < 4; ++j) {
-            c += (u128)a->l[i] * b->l[j] + t[i + j];
-            t[i + j] = (uint64_t)c;
-            c >>= 64;
-        }
-        t[i + 4] = (uint64_t)c;
-    }
-    uint64_t carry2 = 0;
-    for (int i = 0; i < 4; ++i) {
-        uint64_t m = t[i] * PINV;
-        u128 c = 0;
-        for (int j = 0; j < 4; ++j) {
-            c += (u128)m * P[j] + t[i + j];
-            t[i + j] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += (u128)t[i + 4] + carry2;
-        t[i + 4] = (uint64_t)c;
-        carry2 = (uint64_t)(c >> 64);
-    }
+    /* same algorithm, rows unrolled (the compiler keeps everything in registers): 4x4 schoolbook
+     * product to 8 limbs, then 4 Montgomery steps, then one conditional subtraction */
+    const uint64_t a0 = a->l[0], a1 = a->l[1], a2 = a->l[2], a3 = a->l[3];
+    const uint64_t b0 = b->l[0], b1 = b->l[1], b2 = b->l[2], b3 = b->l[3];
+    uint64_t t0, t1, t2, t3, t4, t5, t6, t7, c;
+    MAC(t0, c, a0, b0, 0, 0);   MAC(t1, c, a0, b1, c, 0);   MAC(t2, c, a0, b2, c, 0);   MAC(t3, t4, a0, b3, c, 0);
+    MAC(t1, c, a1, b0, t1, 0);  MAC(t2, c, a1, b1, t2, c);  MAC(t3, c, a1, b2, t3, c);  MAC(t4, t5, a1, b3, t4, c);
+    MAC(t2, c, a2, b0, t2, 0);  MAC(t3, c, a2, b1, t3, c);  MAC(t4, c, a2, b2, t4, c);  MAC(t5, t6, a2, b3, t5, c);
+    MAC(t3, c, a3, b0, t3, 0);  MAC(t4, c, a3, b1, t4, c);  MAC(t5, c, a3, b2, t5, c);  MAC(t6, t7, a3, b3, t6, c);
+    uint64_t m, x, carry2;
+    m = t0 * PINV;
+    MAC(x, c, m, P[0], t0, 0);  MAC(t1, c, m, P[1], t1, c); MAC(t2, c, m, P[2], t2, c); MAC(t3, c, m, P[3], t3, c);
+    { u128 r_ = (u128)t4 + c; t4 = (uint64_t)r_; carry2 = (uint64_t)(r_ >> 64); }
+    m = t1 * PINV;
+    MAC(x, c, m, P[0], t1, 0);  MAC(t2, c, m, P[1], t2, c); MAC(t3, c, m, P[2], t3, c); MAC(t4, c, m, P[3], t4, c);
+    { u128 r_ = (u128)t5 + c + carry2; t5 = (uint64_t)r_; carry2 = (uint64_t)(r_ >> 64); }
+    m = t2 * PINV;
+    MAC(x, c, m, P[0], t2, 0);  MAC(t3, c, m, P[1], t3, c); MAC(t4, c, m, P[2], t4, c); MAC(t5, c, m, P[3], t5, c);
+    { u128 r_ = (u128)t6 + c + carry2; t6 = (uint64_t)r_; carry2 = (uint64_t)(r_ >> 64); }
+    m = t3 * PINV;
+    MAC(x, c, m, P[0], t3, 0);  MAC(t4, c, m, P[1], t4, c); MAC(t5, c, m, P[2], t5, c); MAC(t6, c, m, P[3], t6, c);
+    { u128 r_ = (u128)t7 + c + carry2; t7 = (uint64_t)r_; carry2 = (uint64_t)(r_ >> 64); }
+    (void)x;
     /* inputs with a*b < p*2^256 give a result < 2p < 2^256, so carry2 == 0 here */
-    for (int i = 0; i < 4; ++i) o->l[i] = t[i + 4];
+    o->l[0] = t4; o->l[1] = t5; o->l[2] = t6; o->l[3] = t7;
     if (carry2 || geq_p(o->l)) sub_p(o->l);
 }
 
