@@ -119,6 +119,25 @@ int p252_merkle4_path_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t
 int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
                                    const void* d_positions, size_t depth, void* d_roots, size_t n, void* hip_stream);
 
+/* Batched encryption / decryption: replaces dusk_poseidon::encrypt / decrypt (src/encryption.rs:62-95),
+ * thin wrappers over dusk_safe::encrypt / decrypt with ScalarPermutation and Domain::Encryption.  Per
+ * item: message of `len` scalars, shared secret = the 2 coordinates (u, v) of the JubJub shared point as
+ * BlsScalars (encryption.rs:66-69), nonce = 1 scalar; cipher = len + 1 scalars (masked message + MAC).
+ * Layouts: messages[n][len], secrets[n][2], nonces[n], ciphers[n][len+1], ok[n] bytes (1 = MAC verified;
+ * 0 = dusk_poseidon::Error::DecryptionFailed, src/error.rs:27-29, and that item's message output is
+ * unspecified).  The construction is restated from SAFE with the KAT-pinned sponge mechanics; its
+ * byte-level agreement with the un-vendored dusk-safe 0.3 is UNPINNED (the reference tests only round
+ * trips).  `tag` as everywhere: pass the real crate's value, or p252_encryption_tag() (UNPINNED). */
+int p252_encryption_tag(size_t message_len, uint64_t tag_out[4]);
+int p252_encrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* messages, const uint64_t* secrets,
+                       const uint64_t* nonces, size_t len, uint64_t* ciphers, size_t n);
+int p252_decrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* ciphers, const uint64_t* secrets,
+                       const uint64_t* nonces, size_t len, uint64_t* messages, uint8_t* ok, size_t n);
+int p252_encrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_messages, const void* d_secrets,
+                              const void* d_nonces, size_t len, void* d_ciphers, size_t n, void* hip_stream);
+int p252_decrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
+                              const void* d_nonces, size_t len, void* d_messages, void* d_ok, size_t n, void* hip_stream);
+
 /* ---- constant-table exchange (multi-GPU: rank 0 broadcasts its derived table over RCCL, every
  * rank imports it; byte-identical to what p252_create derives locally) ---- */
 size_t p252_tables_size(void);

@@ -156,6 +156,53 @@ def merkle4_path_batch(tag, leaves, siblings, positions):
     return roots
 
 
+def encryption_tag(message_len):
+    """UNPINNED (see p252_oracle.h)"""
+    out = np.empty(4, dtype=np.uint64)
+    f = lib().p252o_encryption_tag
+    f.argtypes = [ctypes.c_size_t, _u64p]
+    f.restype = ctypes.c_int
+    if f(message_len, _p(out)):
+        raise ValueError("invalid message length")
+    return out
+
+
+def encrypt_batch(tag, messages, secrets, nonces):
+    """messages (n,len,4), secrets (n,2,4), nonces (n,4) -> ciphers (n,len+1,4)"""
+    tag = _c(tag).reshape(4)
+    secrets = _c(secrets).reshape(-1, 2, 4)
+    n = secrets.shape[0]
+    messages = _c(messages).reshape(n, -1, 4)
+    nonces = _c(nonces).reshape(n, 4)
+    ln = messages.shape[1]
+    out = np.empty((n, ln + 1, 4), dtype=np.uint64)
+    f = lib().p252o_encrypt
+    f.argtypes = [_u64p, _u64p, ctypes.c_size_t, _u64p, _u64p, _u64p]
+    f.restype = ctypes.c_int
+    for i in range(n):
+        if f(_p(tag), _p(messages[i]), ln, _p(secrets[i]), _p(nonces[i]), _p(out[i])):
+            raise ValueError("empty message")
+    return out
+
+
+def decrypt_batch(tag, ciphers, secrets, nonces):
+    """ciphers (n,len+1,4) -> (messages (n,len,4), ok (n,) bool)"""
+    tag = _c(tag).reshape(4)
+    secrets = _c(secrets).reshape(-1, 2, 4)
+    n = secrets.shape[0]
+    ciphers = _c(ciphers).reshape(n, -1, 4)
+    nonces = _c(nonces).reshape(n, 4)
+    ln = ciphers.shape[1] - 1
+    out = np.empty((n, ln, 4), dtype=np.uint64)
+    ok = np.zeros(n, dtype=bool)
+    f = lib().p252o_decrypt
+    f.argtypes = [_u64p, _u64p, ctypes.c_size_t, _u64p, _u64p, _u64p]
+    f.restype = ctypes.c_int
+    for i in range(n):
+        ok[i] = f(_p(tag), _p(ciphers[i]), ln, _p(secrets[i]), _p(nonces[i]), _p(out[i])) == 0
+    return out, ok
+
+
 def kat_hash(inputs_le32):
     """inputs: list of 32-byte little-endian canonical strings -> 32-byte LE canonical digest"""
     buf = b"".join(inputs_le32)

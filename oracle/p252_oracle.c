@@ -539,6 +539,120 @@ int p252o_tag(int domain, const size_t *absorb_lens, size_t n_absorbs, size_t ou
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Encryption (src/encryption.rs:62-95 -> dusk_safe::encrypt / decrypt, un-vendored; UNPINNED).
+ * Restated from the SAFE construction with the sponge mechanics the KAT pins:
+ *   io-pattern  [Absorb(2) secret, Absorb(1) nonce, {Squeeze(c), Absorb(c)} per chunk c = min(rate, left),
+ *                Squeeze(1)],  domain separator Domain::Encryption (2^32)
+ *   per chunk:  mask = squeeze(c); cipher = message + mask; absorb(message chunk)
+ *   final:      cipher[len] = squeeze(1)
+ * The reference's own tests (tests/encryption.rs) are round-trip / negative tests only.
+ * ------------------------------------------------------------------------------------------ */
+static inline void fr_sub(fr_t *o, const fr_t *a, const fr_t *b) {
+    u128 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 d = (u128)a->l[i] - b->l[i] - borrow;
+        o->l[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
+    }
+    if (borrow) { /* add p back */
+        u128 c = 0;
+        for (int i = 0; i < 4; ++i) {
+            c += (u128)o->l[i] + P[i];
+            o->l[i] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+}
+
+/* tag for an arbitrary io-pattern given as already-aggregated words (absorb: 0x80000000 | len) */
+static void tag_from_words(const uint32_t *words, size_t n_words, uint64_t sep, uint64_t tag_out[4]) {
+    uint8_t *buf = (uint8_t *)malloc(4 * n_words + 8);
+    for (size_t w = 0; w < n_words; ++w)
+        for (int b = 0; b < 4; ++b) buf[4 * w + b] = (uint8_t)(words[w] >> (24 - 8 * b));
+    for (int b = 0; b < 8; ++b) buf[4 * n_words + b] = (uint8_t)(sep >> (56 - 8 * b));
+    uint8_t h[64];
+    p252o_blake2b512(buf, 4 * n_words + 8, h);
+    free(buf);
+    uint64_t lo[4], hi[4], lom[4], him[4];
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = u64_from_buffer(h, 8 * k);
+        hi[k] = u64_from_buffer(h, 32 + 8 * k);
+    }
+    p252o_from_raw(lo, lom);
+    p252o_from_raw(hi, him);
+    p252o_mul(him, R2, him);
+    p252o_add(lom, him, tag_out);
+}
+
+int p252o_encryption_tag(size_t message_len, uint64_t tag_out[4]) {
+    if (message_len == 0 || message_len >= 0x80000000ULL) return -2;
+    size_t chunks = (message_len + RATE - 1) / RATE;
+    uint32_t *words = (uint32_t *)malloc(sizeof(uint32_t) * (2 * chunks + 2));
+    size_t n = 0;
+    words[n++] = 0x80000000u | 3u; /* Absorb(2) + Absorb(1) aggregate */
+    for (size_t left = message_len; left;) {
+        uint32_t c = left < RATE ? (uint32_t)left : RATE;
+        words[n++] = c;               /* Squeeze(c) */
+        words[n++] = 0x80000000u | c; /* Absorb(c) */
+        left -= c;
+    }
+    words[n++] = 1; /* Squeeze(1) */
+    tag_from_words(words, n, p252o_domain_separator(2), tag_out);
+    free(words);
+    return 0;
+}
+
+static void crypt_start(sponge_t *sp, const uint64_t tag[4], const uint64_t secret[8], const uint64_t nonce[4]) {
+    sponge_start(sp, tag);
+    sponge_absorb(sp, secret, 2);
+    sponge_absorb(sp, nonce, 1);
+}
+
+int p252o_encrypt(const uint64_t tag[4], const uint64_t *message, size_t len, const uint64_t secret[8],
+                  const uint64_t nonce[4], uint64_t *cipher) {
+    if (len == 0) return -2;
+    ensure_constants();
+    sponge_t sp;
+    crypt_start(&sp, tag, secret, nonce);
+    for (size_t off = 0; off < len;) {
+        size_t c = len - off < RATE ? len - off : RATE;
+        uint64_t mask[4 * RATE];
+        sponge_squeeze(&sp, mask, c);
+        for (size_t k = 0; k < c; ++k) p252o_add(message + 4 * (off + k), mask + 4 * k, cipher + 4 * (off + k));
+        sponge_absorb(&sp, message + 4 * off, c);
+        off += c;
+    }
+    sponge_squeeze(&sp, cipher + 4 * len, 1);
+    return 0;
+}
+
+/* 0 = ok, -1 = DecryptionFailed (src/error.rs:27-29) */
+int p252o_decrypt(const uint64_t tag[4], const uint64_t *cipher, size_t len, const uint64_t secret[8],
+                  const uint64_t nonce[4], uint64_t *message) {
+    if (len == 0) return -2;
+    ensure_constants();
+    sponge_t sp;
+    crypt_start(&sp, tag, secret, nonce);
+    for (size_t off = 0; off < len;) {
+        size_t c = len - off < RATE ? len - off : RATE;
+        uint64_t mask[4 * RATE];
+        sponge_squeeze(&sp, mask, c);
+        for (size_t k = 0; k < c; ++k) {
+            fr_t ci, mk, m;
+            memcpy(ci.l, cipher + 4 * (off + k), 32);
+            memcpy(mk.l, mask + 4 * k, 32);
+            fr_sub(&m, &ci, &mk);
+            memcpy(message + 4 * (off + k), m.l, 32);
+        }
+        sponge_absorb(&sp, message + 4 * off, c);
+        off += c;
+    }
+    uint64_t mac[4];
+    sponge_squeeze(&sp, mac, 1);
+    return memcmp(mac, cipher + 4 * len, 32) == 0 ? 0 : -1;
+}
+
 /* hash.rs:164-183 */
 void p252o_truncate250(const uint64_t mont[4], uint64_t out_raw[4]) {
     p252o_to_canonical(mont, out_raw);

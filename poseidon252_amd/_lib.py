@@ -24,6 +24,8 @@ ABI_SYMBOLS = (
     "p252_permute_batch_device", "p252_hash_batch_device", "p252_merkle4_tree_device", "p252_sync",
     "p252_truncate250_device", "p252_merkle4_path_batch", "p252_merkle4_path_batch_device",
     "p252_host_alloc", "p252_host_free",
+    "p252_encryption_tag", "p252_encrypt_batch", "p252_decrypt_batch", "p252_encrypt_batch_device",
+    "p252_decrypt_batch_device",
     "p252_tables_size", "p252_tables_export", "p252_tables_import",
     "p252_domain_separator", "p252_check_io_pattern", "p252_tag", "p252_truncate250", "p252_version",
 )
@@ -63,6 +65,12 @@ def lib():
     L.p252_hash_batch_device.argtypes = [_vp, _u64p, _vp, _sz, _sz, _vp, _sz, _vp]
     L.p252_merkle4_tree_device.argtypes = [_vp, _u64p, _vp, _sz, _vp, _vp, _vp]
     L.p252_sync.argtypes = [_vp, _vp]
+    _u8p2 = ctypes.POINTER(ctypes.c_uint8)
+    L.p252_encryption_tag.argtypes = [_sz, _u64p]
+    L.p252_encrypt_batch.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p, _sz, _u64p, _sz]
+    L.p252_decrypt_batch.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p, _sz, _u64p, _u8p2, _sz]
+    L.p252_encrypt_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
+    L.p252_decrypt_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
     L.p252_host_alloc.argtypes = [_sz]
     L.p252_host_alloc.restype = _vp
     L.p252_host_free.argtypes = [_vp]

@@ -394,6 +394,99 @@ int p252_merkle4_path_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t
     return P252_OK;
 }
 
+// ---- encryption row (src/encryption.rs:62-95) ----
+static int crypt_device(p252_ctx* ctx, bool decrypt, const uint64_t tag[4], const void* d_in, const void* d_secrets,
+                        const void* d_nonces, size_t len, void* d_out, void* d_ok, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (len == 0) return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "encrypt/decrypt: empty message");
+    if (len > 0x7ffffff0u) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: message too long");
+    if (n == 0) return P252_OK;
+    if (!tag || !d_in || !d_secrets || !d_nonces || !d_out || (decrypt && !d_ok))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_crypt(decrypt, ctx->d_tab, tag_arg(tag), d_in, d_secrets, d_nonces, (unsigned)len, d_out, d_ok, n,
+                              (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+int p252_encrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_messages, const void* d_secrets,
+                              const void* d_nonces, size_t len, void* d_ciphers, size_t n, void* hip_stream) {
+    return crypt_device(ctx, false, tag, d_messages, d_secrets, d_nonces, len, d_ciphers, nullptr, n, hip_stream);
+}
+
+int p252_decrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
+                              const void* d_nonces, size_t len, void* d_messages, void* d_ok, size_t n, void* hip_stream) {
+    return crypt_device(ctx, true, tag, d_ciphers, d_secrets, d_nonces, len, d_messages, d_ok, n, hip_stream);
+}
+
+static int crypt_host(p252_ctx* ctx, bool decrypt, const uint64_t tag[4], const uint64_t* in, const uint64_t* secrets,
+                      const uint64_t* nonces, size_t len, uint64_t* out, uint8_t* ok, size_t n) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (len == 0) return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "encrypt/decrypt: empty message");
+    if (n == 0) return P252_OK;
+    if (!tag || !in || !secrets || !nonces || !out || (decrypt && !ok))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t in_b = n * (decrypt ? len + 1 : len) * 32, out_b = n * (decrypt ? len : len + 1) * 32;
+    const size_t sec_b = n * 64, non_b = n * 32, ok_b = (n + 15) & ~(size_t)15;
+    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_b + sec_b + non_b);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_b + ok_b);
+    if (rc) return rc;
+    char* di = static_cast<char*>(ctx->d_in);
+    char* dout = static_cast<char*>(ctx->d_out);
+    HIP_TRY(ctx, hipMemcpy(di, in, in_b, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(di + in_b, secrets, sec_b, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(di + in_b + sec_b, nonces, non_b, hipMemcpyHostToDevice));
+    rc = crypt_device(ctx, decrypt, tag, di, di + in_b, di + in_b + sec_b, len, dout, dout + out_b, n, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(out, dout, out_b, hipMemcpyDeviceToHost));
+    if (decrypt) HIP_TRY(ctx, hipMemcpy(ok, dout + out_b, n, hipMemcpyDeviceToHost));
+    return P252_OK;
+}
+
+int p252_encrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* messages, const uint64_t* secrets,
+                       const uint64_t* nonces, size_t len, uint64_t* ciphers, size_t n) {
+    return crypt_host(ctx, false, tag, messages, secrets, nonces, len, ciphers, nullptr, n);
+}
+
+int p252_decrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* ciphers, const uint64_t* secrets,
+                       const uint64_t* nonces, size_t len, uint64_t* messages, uint8_t* ok, size_t n) {
+    return crypt_host(ctx, true, tag, ciphers, secrets, nonces, len, messages, ok, n);
+}
+
+// UNPINNED: tag of the encryption io-pattern [Absorb(2)+Absorb(1) -> Absorb(3), {Squeeze(c), Absorb(c)}*, Squeeze(1)]
+int p252_encryption_tag(size_t message_len, uint64_t tag_out[4]) {
+    if (!tag_out) return P252_ERR_INVALID_ARGUMENT;
+    if (message_len == 0) return P252_ERR_INVALID_IO_PATTERN;
+    if (message_len >= 0x80000000ULL) return P252_ERR_INVALID_ARGUMENT;
+    std::vector<uint8_t> buf;
+    auto word = [&](uint32_t w) {
+        for (int b = 0; b < 4; ++b) buf.push_back((uint8_t)(w >> (24 - 8 * b)));
+    };
+    word(0x80000000u | 3u);
+    for (size_t left = message_len; left;) {
+        const uint32_t c = left < 4 ? (uint32_t)left : 4u;
+        word(c);
+        word(0x80000000u | c);
+        left -= c;
+    }
+    word(1);
+    uint64_t sep = 0;
+    p252_domain_separator(P252_DOMAIN_ENCRYPTION, &sep);
+    for (int b = 0; b < 8; ++b) buf.push_back((uint8_t)(sep >> (56 - 8 * b)));
+    uint8_t h[64];
+    blake2b_512(buf.data(), buf.size(), h);
+    uint64_t lo[4], hi[4];
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = u64_from_buffer(h, 8 * k);
+        hi[k] = u64_from_buffer(h, 32 + 8 * k);
+    }
+    FrHost r = FrHost::from_raw(lo) + FrHost::from_raw(hi) * FrHost::pow2(256);
+    std::memcpy(tag_out, r.l, 32);
+    return P252_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // constant-table exchange
 // ------------------------------------------------------------------------------------------

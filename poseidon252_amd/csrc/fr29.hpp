@@ -170,6 +170,13 @@ P252_HD void add_c(E29& x, CP c) {
 }
 P252_HD void add_e(E29& x, const E29& y) { add_c(x, y.d); }
 
+// x -= y (scalar.rs:67-74, Encryption::subtract); signs are tolerated, result normalised
+P252_HD void sub_e(E29& x, const E29& y) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) x.d[k] -= y.d[k];
+    normalize(x);
+}
+
 P252_HD E29 e29_zero() {
     E29 r;
 #pragma unroll

@@ -120,6 +120,64 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
     }
 }
 
+// ---- batched encryption / decryption (src/encryption.rs:62-95 -> dusk_safe::encrypt / decrypt; the
+// construction is restated from SAFE, UNPINNED like the tag — DESIGN.md §5).  Sponge in duplex use:
+// state = [tag, secret.u, secret.v, nonce, 0]; per chunk of <= 4 elements: permute, mask = state[1..],
+// cipher = message + mask, message absorbed (state[1+k] becomes cipher_k); final permute, MAC = state[1].
+// Encrypt: in = messages[n][len], out = ciphers[n][len+1].  Decrypt: in = ciphers[n][len+1],
+// out = messages[n][len], flags[i] = 1 iff the recomputed MAC equals cipher[len] (else DecryptionFailed). ----
+template <bool DECRYPT>
+__global__ void __launch_bounds__(P252_BLOCK) k_crypt(const int32_t* __restrict__ tab, TagArg tag,
+                                                      const Scalar32* __restrict__ in,
+                                                      const Scalar32* __restrict__ secrets,
+                                                      const Scalar32* __restrict__ nonces, unsigned len,
+                                                      Scalar32* __restrict__ out, uint8_t* __restrict__ flags,
+                                                      size_t n) {
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const Scalar32* my_in = in + idx * (DECRYPT ? len + 1 : len);
+    Scalar32* my_out = out + idx * (DECRYPT ? len : len + 1);
+    E29 s[WIDTH];
+    s[0] = from_mont4(tag.w);
+    s[1] = load_scalar(secrets + 2 * idx);
+    s[2] = load_scalar(secrets + 2 * idx + 1);
+    s[3] = load_scalar(nonces + idx);
+    s[4] = e29_zero();
+    const unsigned chunks = (len + 3) / 4;
+#pragma unroll 1
+    for (unsigned it = 0; it <= chunks; ++it) {
+        hades_permute<0x1fu, 1>(s, tab);
+        if (it < chunks) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned e = it * 4 + k;
+                if (e < len) {
+                    const E29 x = load_scalar(my_in + e);
+                    if (!DECRYPT) {
+                        add_e(s[1 + k], x);  // cipher_k = mask_k + message_k, and it IS the absorbed state
+                        store_scalar(my_out + e, s[1 + k]);
+                    } else {
+                        E29 m = x;
+                        sub_e(m, s[1 + k]);  // message_k = cipher_k - mask_k
+                        store_scalar(my_out + e, m);
+                        s[1 + k] = x;        // mask_k + message_k == cipher_k
+                    }
+                }
+            }
+        } else if (!DECRYPT) {
+            store_scalar(my_out + len, s[1]);
+        } else {
+            uint32_t w[8];
+            to_mont4(s[1], w);
+            const uint4 lo = *reinterpret_cast<const uint4*>(my_in + len);
+            const uint4 hi = *(reinterpret_cast<const uint4*>(my_in + len) + 1);
+            const bool same = w[0] == lo.x && w[1] == lo.y && w[2] == lo.z && w[3] == lo.w && w[4] == hi.x &&
+                              w[5] == hi.y && w[6] == hi.z && w[7] == hi.w;
+            flags[idx] = same ? 1 : 0;
+        }
+    }
+}
+
 // ---- finalize_truncated post-processing (hash.rs:164-183) on device-resident digests:
 // canonical value (Montgomery form dropped) & (2^250 - 1), written as the raw limbs that
 // JubJubScalar::from_raw receives.  redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256 = the canonical value. ----
@@ -204,6 +262,22 @@ hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, 
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_sponge, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                        static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_crypt(bool decrypt, const int32_t* tab, const TagArg& tag, const void* in, const void* secrets,
+                        const void* nonces, unsigned len, void* out, void* flags, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (decrypt)
+        hipLaunchKernelGGL(k_crypt<true>, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(in), static_cast<const Scalar32*>(secrets),
+                           static_cast<const Scalar32*>(nonces), len, static_cast<Scalar32*>(out),
+                           static_cast<uint8_t*>(flags), n);
+    else
+        hipLaunchKernelGGL(k_crypt<false>, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(in), static_cast<const Scalar32*>(secrets),
+                           static_cast<const Scalar32*>(nonces), len, static_cast<Scalar32*>(out),
+                           static_cast<uint8_t*>(flags), n);
     return hipGetLastError();
 }
 

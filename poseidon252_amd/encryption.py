@@ -1,0 +1,83 @@
+"""Host-side mirror of `dusk_poseidon::{encrypt, decrypt}` (src/encryption.rs:62-95), single and batched.
+
+The reference wraps `dusk_safe::encrypt/decrypt` with `ScalarPermutation`, `Domain::Encryption` and the
+two coordinates of a JubJub shared point as the secret.  dusk-safe is not vendored in the reference and
+its tests only check round trips and failures (tests/encryption.rs:30-115), so the construction below —
+SAFE duplex: per <=4-element chunk squeeze a mask, add it to the message, absorb the message; finally
+squeeze one element as MAC — is restated from the SAFE design with the KAT-pinned sponge mechanics and is
+UNPINNED at the byte level.  All hashing happens on the GPU.
+
+shared_secret: (2,4) uint64 — the (u, v) coordinates of the shared JubJubAffine as BlsScalars
+               (encryption.rs:66-69: `shared_secret.get_u(), shared_secret.get_v()`); nonce: (4,) uint64.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .hash import Context, Error, _as_scalars, _raise
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class DecryptionFailed(Error):
+    """Error::DecryptionFailed (src/error.rs:27-29)"""
+
+
+def encryption_tag(message_len):
+    """Safe::tag of the encryption io-pattern for a message of `message_len` scalars.  UNPINNED recipe."""
+    out = np.empty(4, dtype=np.uint64)
+    rc = _lib.lib().p252_encryption_tag(int(message_len), out.ctypes.data_as(_u64p))
+    if rc:
+        _raise(rc)
+    return out
+
+
+def encrypt_batch(messages, shared_secrets, nonces, ctx=None, tag=None):
+    """messages (n,len,4), shared_secrets (n,2,4), nonces (n,4) -> ciphers (n,len+1,4)"""
+    secrets = _as_scalars(shared_secrets).reshape(-1, 2, 4)
+    n = secrets.shape[0]
+    msgs = _as_scalars(messages).reshape(n, -1, 4) if n else _as_scalars(messages).reshape(0, 1, 4)
+    non = _as_scalars(nonces).reshape(n, 4)
+    ln = msgs.shape[1]
+    ctx = ctx or Context.default()
+    tag = encryption_tag(ln) if tag is None else _as_scalars(tag).reshape(4)
+    out = np.empty((n, ln + 1, 4), dtype=np.uint64)
+    ctx._check(_lib.lib().p252_encrypt_batch(ctx._h, tag.ctypes.data_as(_u64p), msgs.ctypes.data_as(_u64p),
+                                             secrets.ctypes.data_as(_u64p), non.ctypes.data_as(_u64p), ln,
+                                             out.ctypes.data_as(_u64p), n))
+    return out
+
+
+def decrypt_batch(ciphers, shared_secrets, nonces, ctx=None, tag=None):
+    """ciphers (n,len+1,4) -> (messages (n,len,4), ok (n,) bool); ok[i] False = DecryptionFailed for item i"""
+    secrets = _as_scalars(shared_secrets).reshape(-1, 2, 4)
+    n = secrets.shape[0]
+    cph = _as_scalars(ciphers).reshape(n, -1, 4)
+    non = _as_scalars(nonces).reshape(n, 4)
+    ln = cph.shape[1] - 1
+    ctx = ctx or Context.default()
+    if ln < 1:
+        ctx._check(_lib.ERR_INVALID_IO_PATTERN)
+    tag = encryption_tag(ln) if tag is None else _as_scalars(tag).reshape(4)
+    out = np.empty((n, ln, 4), dtype=np.uint64)
+    ok = np.zeros(n, dtype=np.uint8)
+    ctx._check(_lib.lib().p252_decrypt_batch(ctx._h, tag.ctypes.data_as(_u64p), cph.ctypes.data_as(_u64p),
+                                             secrets.ctypes.data_as(_u64p), non.ctypes.data_as(_u64p), ln,
+                                             out.ctypes.data_as(_u64p), ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n))
+    return out, ok.astype(bool)
+
+
+def encrypt(message, shared_secret, nonce, ctx=None, tag=None):
+    """`dusk_poseidon::encrypt` (encryption.rs:62-76): Vec<BlsScalar> of message.len() + 1"""
+    m = _as_scalars(message).reshape(-1, 4)
+    return encrypt_batch(m[None], _as_scalars(shared_secret).reshape(1, 2, 4), _as_scalars(nonce).reshape(1, 4), ctx=ctx, tag=tag)[0]
+
+
+def decrypt(cipher, shared_secret, nonce, ctx=None, tag=None):
+    """`dusk_poseidon::decrypt` (encryption.rs:81-95): the message, or raises DecryptionFailed"""
+    c = _as_scalars(cipher).reshape(-1, 4)
+    msg, ok = decrypt_batch(c[None], _as_scalars(shared_secret).reshape(1, 2, 4), _as_scalars(nonce).reshape(1, 4), ctx=ctx, tag=tag)
+    if not ok[0]:
+        raise DecryptionFailed("DecryptionFailed")
+    return msg[0]
