@@ -128,6 +128,50 @@ struct FrHost {
         uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
         return pow(e);
     }
+    FrHost pow5() const {
+        FrHost x2 = *this * *this;
+        return x2 * x2 * *this;
+    }
+    bool is_square() const {  // Euler criterion
+        uint64_t e[4];        // (p - 1) / 2
+        for (int i = 0; i < 4; ++i) e[i] = (P[i] >> 1) | (i < 3 ? P[i + 1] << 63 : 0);
+        return is_zero() || pow(e) == one();
+    }
+    // Tonelli-Shanks; p - 1 = 2^32 * q with q odd.  Precondition: is_square().
+    FrHost sqrt() const {
+        if (is_zero()) return *this;
+        uint64_t q[4], qp1h[4];  // q = (p - 1) >> 32 ; (q + 1) / 2
+        const uint64_t pm1[4] = {P[0] - 1, P[1], P[2], P[3]};
+        for (int i = 0; i < 4; ++i) q[i] = (pm1[i] >> 32) | (i < 3 ? pm1[i + 1] << 32 : 0);
+        uint64_t t4[4] = {q[0] + 1, q[1], q[2], q[3]};  // q odd -> no carry out of limb 0 beyond +1 on an odd value
+        for (int i = 0; i < 4; ++i) qp1h[i] = (t4[i] >> 1) | (i < 3 ? t4[i + 1] << 63 : 0);
+        FrHost z = from_u64(2);
+        while (z.is_square()) z = z + one();
+        unsigned m = 32;
+        FrHost c = z.pow(q), t = pow(q), r = pow(qp1h);
+        const FrHost I = one();
+        while (!(t == I)) {
+            unsigned i = 0;
+            FrHost t2 = t;
+            while (!(t2 == I)) {
+                t2 = t2 * t2;
+                ++i;
+            }
+            FrHost b = c;
+            for (unsigned k = 0; k + i + 1 < m; ++k) b = b * b;
+            m = i;
+            c = b * b;
+            t = t * c;
+            r = r * b;
+        }
+        return r;
+    }
+    // any x with x^4 == *this.  Precondition: *this is a 4th power.
+    FrHost fourth_root() const {
+        FrHost r = sqrt();
+        if (!r.is_square()) r = r.neg();
+        return r.sqrt();
+    }
     // 2^k as a field element
     static FrHost pow2(unsigned k) {
         FrHost r = one(), two = from_u64(2);

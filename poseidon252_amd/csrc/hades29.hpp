@@ -23,8 +23,9 @@ namespace p252 {
 // One full round: state <- Mat * sbox(state) + add     (ARC of this round was folded into the
 // previous layer's `add`).  5 S-boxes (15 mults, 15 redc) + 25 products + 5 redc.
 // ROWS < 5 computes only the first ROWS output lanes (the last round of a digest needs lane 1 only).
+// unit0: column 0 of `mat` is the constant tau (scaled schedule) — its 5 products are plain additions.
 template <class TP>
-P252_HD void full_round(E29 s[WIDTH], TP mat, TP add, unsigned rows = 0x1fu) {
+P252_HD void full_round(E29 s[WIDTH], TP mat, TP add, unsigned rows = 0x1fu, bool unit0 = false) {
     E29 v[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) v[i] = sbox(s[i]);
@@ -33,8 +34,12 @@ P252_HD void full_round(E29 s[WIDTH], TP mat, TP add, unsigned rows = 0x1fu) {
         if (!((rows >> k) & 1u)) continue;  // wave-uniform
         A29 t;
         acc_set_hi_c(t, add + k * NL);
+        if (unit0)  // wave-uniform
+            acc_add_hi(t, v[0]);
+        else
+            acc_mul(t, v[0], mat + (k * WIDTH) * NL);
 #pragma unroll
-        for (int j = 0; j < WIDTH; ++j) acc_mul(t, v[j], mat + (k * WIDTH + j) * NL);  // MDS[k][j] * state[j]
+        for (int j = 1; j < WIDTH; ++j) acc_mul(t, v[j], mat + (k * WIDTH + j) * NL);  // MDS[k][j] * state[j]
         s[k] = redc(t);
     }
 }
@@ -105,7 +110,12 @@ P252_HD void arma_round(E29 h[9], TP tab, int q) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc_mul(t, h[m], tab + Lay::ARMA_A + m * NL);
 #pragma unroll
-    for (int n = 0; n < 5; ++n) acc_mul(t, h[4 + n], tab + Lay::ARMA_BETA + n * NL);
+    for (int n = 0; n < 5; ++n) {
+        if (n == 3)
+            acc_add_hi(t, h[4 + n]);  // scaled schedule: beta_3 * lam^4 == tau, the free constant
+        else
+            acc_mul(t, h[4 + n], tab + Lay::ARMA_BETA + n * NL);
+    }
     const E29 unew = redc(t);
     h[3] = h[2];
     h[2] = h[1];
@@ -125,7 +135,10 @@ P252_HD void arma_exit(const E29 h[9], E29 s[WIDTH], TP tab) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // Gy[i][r] multiplies u_{58+r} = h[3-r]; Gv[i][r] multiplies v_{57+r} = h[7-r]
             acc_mul(t, h[3 - r], tab + Lay::EXIT_GY + (i * 4 + r) * NL);
-            acc_mul(t, h[7 - r], tab + Lay::EXIT_GV + (i * 4 + r) * NL);
+            if (r == 3)
+                acc_add_hi(t, h[7 - r]);  // scaled schedule: the coefficient of v_60 is tau in every row
+            else
+                acc_mul(t, h[7 - r], tab + Lay::EXIT_GV + (i * 4 + r) * NL);
         }
         s[i] = redc(t);
     }
@@ -189,8 +202,10 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
             const bool entry = step == RF - 1;
             const int f = step < RF ? step : step - STEP_EXIT - 1 + RF;
             const unsigned rows = step == STEP_END - 1 ? last_rows : 0x1fu;
-            full_round(s, tab + (entry ? Lay::MDS_ENTRY : Lay::MDS),
-                       tab + (entry ? Lay::ENTRY_ADD : Lay::FULL_ADD + f * WIDTH * NL), rows);
+            // scaled schedule: one matrix per round; column 0 is the free constant except in the entry
+            // round (f = 3) and in the last round (f = 7, which must output the true state)
+            full_round(s, tab + Lay::SC_MATS + f * WIDTH * WIDTH * NL, tab + Lay::SC_ADDS + f * WIDTH * NL, rows,
+                       f != RF - 1 && f != FULL_ROUNDS - 1);
             if (entry) h[0] = s[4];  // u_1
         } else if (step < STEP_ARMA0) {
             entry_round(s, h, tab);

@@ -45,6 +45,26 @@ size_t ht_tables_raw(uint64_t* out) {
     return k;
 }
 
+// scaled-schedule constants as Montgomery limbs (for comparison with tests/pymodel.py::derive_scaled):
+//  lam, sc_mats[8][25], sc_adds[8][5], entry_g[4], arma_a[4], arma_beta[5], arma_kappa[56], exit_gy[16], exit_gv[16], exit_add[4]
+size_t ht_tables_scaled_raw(uint64_t* out) {
+    HadesTables T;
+    derive_tables(ARC_BIN, MDS_BIN, T);
+    size_t k = 0;
+    auto put = [&](const FrHost& v) { std::memcpy(out + 4 * k++, v.l, 32); };
+    put(T.lam);
+    for (int f = 0; f < 8; ++f) for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) put(T.sc_mats[f][i][j]);
+    for (int f = 0; f < 8; ++f) for (int i = 0; i < 5; ++i) put(T.sc_adds[f][i]);
+    for (int n = 0; n < 4; ++n) put(T.entry_g[n]);
+    for (int m = 0; m < 4; ++m) put(T.arma_a[m]);
+    for (int n = 0; n < 5; ++n) put(T.arma_beta[n]);
+    for (int q = 0; q < 56; ++q) put(T.arma_kappa[q]);
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.exit_gy[i][r]);
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.exit_gv[i][r]);
+    for (int i = 0; i < 4; ++i) put(T.exit_add[i]);
+    return k;
+}
+
 void ht_roundtrip29(const uint64_t* in, uint64_t* out, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         E29 e = from_mont4(reinterpret_cast<const uint32_t*>(in + 4 * i));

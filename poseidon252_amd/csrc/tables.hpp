@@ -50,9 +50,18 @@ struct HadesTables {
     FrHost exit_add[4];
     // ---- direct entry into the ARMA phase: full round 3 outputs the projections p_q = c^T A^(q-1) L_1
     //      (rows 0..3) and u_1 (row 4); then u_{q+1} = p_q + sum_{n<q} g_n v_{q-n}  for q = 1..4 ----
-    FrHost mds_entry[WIDTH][WIDTH];   // rows 0..3: (c^T A^(q-1)) * M[0..3][:], row 4: M[4][:]
-    FrHost entry_add[WIDTH];          // k_2, k_3, k_4, k_5, k_1
-    FrHost entry_g[4];                // Markov parameters g_0..g_3
+    FrHost mds_entry[WIDTH][WIDTH];   // rows 0..3: (c^T A^(q-1)) * M[0..3][:], row 4: M[4][:]   (unscaled)
+    FrHost entry_add[WIDTH];          // k_2, k_3, k_4, k_5, k_1                                  (unscaled)
+    FrHost entry_g[4];                // Markov parameters g_0..g_3 (scaled by lam^4, see below)
+    // ---- state re-scaling (x^5 is homogeneous: a diagonal scaling commutes with an S-box layer up to 5th
+    //      powers).  After every linear layer the state is re-scaled so that ONE coefficient per output row
+    //      equals tau = 2^-20, the value whose device encoding is exactly 2^261: that product becomes a
+    //      plain addition.  arma_beta / arma_kappa / exit_* / entry_g above hold the SCALED values;
+    //      sc_mats / sc_adds are the per-round matrices and additive constants of the 8 full rounds
+    //      (index 3 = the entry matrix).  Column 0 of rounds 0,1,2,4,5,6 is tau. ----
+    FrHost sc_mats[FULL_ROUNDS][WIDTH][WIDTH];
+    FrHost sc_adds[FULL_ROUNDS][WIDTH];
+    FrHost lam;                       // time-invariant scale of the partial phase: beta_3 * lam^4 == tau
 };
 
 inline uint64_t u64_from_buffer(const unsigned char* buf, size_t i) {  // src/hades.rs:40-51
@@ -269,6 +278,61 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
     for (int q = 1; q <= 4; ++q) T.entry_add[q - 1] = kq[q + 1];
     T.entry_add[4] = kq[1];
     for (int n = 0; n < 4; ++n) T.entry_g[n] = g[n];
+
+    // ---- (4) state re-scaling (see HadesTables).  tests/pymodel.py::derive_scaled is the big-int twin. ----
+    const FrHost tau = FrHost::pow2(20).inv();
+    const FrHost tau_inv = FrHost::pow2(20);
+    T.lam = (tau * T.arma_beta[3].inv()).fourth_root();  // exists: checked in tests (and asserted below by use)
+    const FrHost lam = T.lam, lam_inv = lam.inv();
+    const FrHost lam4 = (lam * lam) * (lam * lam), lam5 = lam4 * lam;
+    FrHost L[WIDTH];
+    for (int i = 0; i < WIDTH; ++i) L[i] = FrHost::one();
+    for (int r = 0; r < RF - 1; ++r) {  // opening rounds 0..2: column 0 normalised
+        FrHost L5[WIDTH], Ln[WIDTH];
+        for (int j = 0; j < WIDTH; ++j) L5[j] = L[j].pow5();
+        for (int i = 0; i < WIDTH; ++i) Ln[i] = M[i][0] * L5[0] * tau_inv;
+        for (int i = 0; i < WIDTH; ++i) {
+            const FrHost li = Ln[i].inv();
+            for (int j = 0; j < WIDTH; ++j) T.sc_mats[r][i][j] = li * M[i][j] * L5[j];
+            T.sc_adds[r][i] = li * C[r + 1][i];
+        }
+        for (int i = 0; i < WIDTH; ++i) L[i] = Ln[i];
+    }
+    {  // round 3 = entry matrix, scaled by 1/lam (its outputs are the partial phase's scaled projections and u_1)
+        FrHost L5[WIDTH];
+        for (int j = 0; j < WIDTH; ++j) L5[j] = L[j].pow5();
+        for (int i = 0; i < WIDTH; ++i) {
+            for (int j = 0; j < WIDTH; ++j) T.sc_mats[RF - 1][i][j] = lam_inv * T.mds_entry[i][j] * L5[j];
+            T.sc_adds[RF - 1][i] = lam_inv * T.entry_add[i];
+        }
+    }
+    for (int n = 0; n < 4; ++n) T.entry_g[n] = g[n] * lam4;
+    for (int n = 0; n < 5; ++n) T.arma_beta[n] = T.arma_beta[n] * lam4;  // arma_beta[3] == tau now
+    for (int q = 0; q < PARTIAL_ROUNDS - 4; ++q) T.arma_kappa[q] = T.arma_kappa[q] * lam_inv;
+    FrHost Lc[WIDTH];  // scale of the state leaving the exit: rows 0..3 normalise the coefficient of v_60
+    for (int i = 0; i < 4; ++i) Lc[i] = T.exit_gv[i][3] * lam5 * tau_inv;
+    Lc[4] = lam;
+    for (int i = 0; i < 4; ++i) {
+        const FrHost li = Lc[i].inv();
+        for (int r = 0; r < 4; ++r) {
+            T.exit_gy[i][r] = li * T.exit_gy[i][r] * lam;
+            T.exit_gv[i][r] = li * T.exit_gv[i][r] * lam5;
+        }
+        T.exit_add[i] = li * T.exit_add[i];
+    }
+    for (int i = 0; i < WIDTH; ++i) L[i] = Lc[i];
+    for (int f = RF; f < FULL_ROUNDS; ++f) {  // closing rounds: 4,5,6 normalised, 7 outputs the true state
+        const bool last = f == FULL_ROUNDS - 1;
+        FrHost L5[WIDTH], Ln[WIDTH];
+        for (int j = 0; j < WIDTH; ++j) L5[j] = L[j].pow5();
+        for (int i = 0; i < WIDTH; ++i) Ln[i] = last ? FrHost::one() : M[i][0] * L5[0] * tau_inv;
+        for (int i = 0; i < WIDTH; ++i) {
+            const FrHost li = Ln[i].inv();
+            for (int j = 0; j < WIDTH; ++j) T.sc_mats[f][i][j] = li * M[i][j] * L5[j];
+            T.sc_adds[f][i] = last ? FrHost::zero() : li * C[f + PARTIAL_ROUNDS + 1][i];
+        }
+        for (int i = 0; i < WIDTH; ++i) L[i] = Ln[i];
+    }
 }
 
 // =============================================================================================
@@ -295,9 +359,9 @@ struct Tab29Layout {
     static constexpr int EXIT_GY = ARMA_KAPPA + (PARTIAL_ROUNDS - 4) * NL;    // [4][4][9] MP
     static constexpr int EXIT_GV = EXIT_GY + 16 * NL;                         // [4][4][9] MS
     static constexpr int EXIT_ADD = EXIT_GV + 16 * NL;                        // [4][9] A
-    static constexpr int MDS_ENTRY = EXIT_ADD + 4 * NL;                       // [5][5][9] MS
-    static constexpr int ENTRY_ADD = MDS_ENTRY + WIDTH * WIDTH * NL;          // [5][9] A
-    static constexpr int ENTRY_G = ENTRY_ADD + WIDTH * NL;                    // [4][9] MS  (g_0..g_3)
+    static constexpr int SC_MATS = EXIT_ADD + 4 * NL;                         // [8][5][5][9] MS  per-round matrices
+    static constexpr int SC_ADDS = SC_MATS + FULL_ROUNDS * WIDTH * WIDTH * NL;  // [8][5][9] A
+    static constexpr int ENTRY_G = SC_ADDS + FULL_ROUNDS * WIDTH * NL;        // [4][9] MS  (g_0..g_3, scaled)
     static constexpr int TOTAL = ENTRY_G + 4 * NL;
 };
 
@@ -367,10 +431,11 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
             put(Lay::EXIT_GV + (i * 4 + r) * NL, T.exit_gv[i][r], fMS);
         }
     for (int i = 0; i < 4; ++i) put(Lay::EXIT_ADD + i * NL, T.exit_add[i], fA);
-    for (int i = 0; i < WIDTH; ++i) {
-        for (int j = 0; j < WIDTH; ++j) put(Lay::MDS_ENTRY + (i * WIDTH + j) * NL, T.mds_entry[i][j], fMS);
-        put(Lay::ENTRY_ADD + i * NL, T.entry_add[i], fA);
-    }
+    for (int f = 0; f < FULL_ROUNDS; ++f)
+        for (int i = 0; i < WIDTH; ++i) {
+            for (int j = 0; j < WIDTH; ++j) put(Lay::SC_MATS + ((f * WIDTH + i) * WIDTH + j) * NL, T.sc_mats[f][i][j], fMS);
+            put(Lay::SC_ADDS + (f * WIDTH + i) * NL, T.sc_adds[f][i], fA);
+        }
     for (int n = 0; n < 4; ++n) put(Lay::ENTRY_G + n * NL, T.entry_g[n], fMS);
     return tab;
 }
@@ -397,7 +462,8 @@ inline double max_column_bound29(const int32_t* tab) {
             if (col[k] + REDC > worst) worst = col[k] + REDC;
     };
     group({Lay::ENTRY_G, Lay::ENTRY_G + NL, Lay::ENTRY_G + 2 * NL, Lay::ENTRY_G + 3 * NL});
-    for (int base : {Lay::MDS, Lay::MDS_PRE, Lay::MDS_ENTRY})
+    for (int base : {Lay::MDS, Lay::MDS_PRE, Lay::SC_MATS, Lay::SC_MATS + 225 * 1, Lay::SC_MATS + 225 * 2, Lay::SC_MATS + 225 * 3,
+                     Lay::SC_MATS + 225 * 4, Lay::SC_MATS + 225 * 5, Lay::SC_MATS + 225 * 6, Lay::SC_MATS + 225 * 7})
         for (int k = 0; k < WIDTH; ++k)
             group({base + (k * 5 + 0) * NL, base + (k * 5 + 1) * NL, base + (k * 5 + 2) * NL, base + (k * 5 + 3) * NL,
                    base + (k * 5 + 4) * NL});

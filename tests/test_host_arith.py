@@ -122,3 +122,28 @@ def test_static_column_bound(hosttest_lib):
     hosttest_lib.ht_max_column_bound29.restype = ctypes.c_double
     b = hosttest_lib.ht_max_column_bound29()
     assert 60 < math.log2(b) < 62.9, math.log2(b)
+
+
+def test_scaled_tables_match_bigint_derivation(oracle_mod, hosttest_lib):
+    """csrc/tables.hpp step (4) (state re-scaling: one free coefficient per row) vs tests/pymodel.py::derive_scaled,
+    using the library's choice among the four 4th roots"""
+    n = 1 + 200 + 40 + 4 + 4 + 5 + 56 + 16 + 16 + 4
+    raw = np.empty((n, 4), dtype=np.uint64)
+    hosttest_lib.ht_tables_scaled_raw.restype = ctypes.c_size_t
+    assert hosttest_lib.ht_tables_scaled_raw(p(raw)) == n
+    got = [oracle_mod.int_from_mont(v) for v in raw]
+    C, M = pymodel.load_constants()
+    lam = got[0]
+    S = pymodel.derive_scaled(C, M, lam=lam)
+    exp = [lam] + [S["mats"][f][i][j] for f in range(8) for i in range(5) for j in range(5)]
+    exp += [S["adds"][f][i] for f in range(8) for i in range(5)]
+    exp += list(S["entry_g"]) + list(S["arma_a"]) + list(S["arma_beta"]) + [S["arma_kappa"][q] for q in range(6, 62)]
+    exp += [S["exit_gy"][i][r] for i in range(4) for r in range(4)] + [S["exit_gv"][i][r] for i in range(4) for r in range(4)]
+    exp += list(S["exit_add"])
+    assert got == exp
+    # the normalised coefficients are exactly tau = 2^-20 (device encoding 2^261 -> a plain addition)
+    assert S["arma_beta"][3] == pymodel.TAU and all(S["exit_gv"][i][3] == pymodel.TAU for i in range(4))
+    assert all(S["mats"][f][i][0] == pymodel.TAU for f in (0, 1, 2, 4, 5, 6) for i in range(5))
+    rng = random.Random(12)
+    x = [rng.randrange(P) for _ in range(5)]
+    assert pymodel.perm_scaled(x, C, M, S) == pymodel.perm_reference(x, C, M)
