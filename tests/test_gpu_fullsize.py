@@ -83,6 +83,14 @@ def test_random_shapes_sweep(gpu_ctx, oracle_mod):
         assert np.array_equal(got, oracle_mod.hash_batch(tag, m, in_len, out_len)), (n, in_len, out_len)
 
 
+def test_long_messages(gpu_ctx, oracle_mod):
+    """few, very long messages: 1,025 and 4,099 scalars absorbed sequentially (257 / 1,025 permutations per lane)"""
+    for n, in_len, out_len in [(3, 1025, 9), (2, 4099, 1)]:
+        tag = oracle_mod.fill_random(31 + in_len, 1)[0]
+        m = oracle_mod.fill_random(32 + in_len, n * in_len).reshape(n, in_len, 4)
+        assert np.array_equal(gpu_ctx.hash_batch(tag, m, in_len, out_len), oracle_mod.hash_batch(tag, m, in_len, out_len))
+
+
 def test_two_contexts_and_streams(gpu_ctx, oracle_mod):
     """distinct contexts are independent; work on a non-default torch stream is ordered on that stream"""
     import torch
