@@ -1,0 +1,74 @@
+"""Regression guards on what hipcc generates for gfx950 (runs on CPU: hipcc cross-compiles), and a
+loose throughput floor on the GPU.  The kernels are VALU-issue bound, so the things that silently cost
+performance are: private-memory (scratch) use when an unroll budget is missed, a duplicated round body
+blowing the instruction cache, and products lowered to two multiply-adds."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "poseidon252_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    from poseidon252_amd import build as b
+    b._gen_assets()
+    out = tmp_path_factory.mktemp("isa") / "kernels.s"
+    cmd = [b._hipcc()] + [f for f in b.HIPCC_FLAGS if f != "-fPIC"] + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                                                                      "-o", str(out), os.path.join(CSRC, "kernels.hip")]
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    return open(out).read(), proc.stderr
+
+
+def test_no_scratch_and_register_budget(isa):
+    text, remarks = isa
+    names = re.findall(r"Function Name: (\S+)", remarks)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", remarks)]
+    vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", remarks)]
+    assert len(names) >= 6 and len(scratch) == len(names) == len(vgprs)
+    for n, s, v in zip(names, scratch, vgprs):
+        assert s == 0, "%s uses %d B of scratch per lane (an unroll fell back to a loop?)" % (n, s)
+        assert v <= 256, "%s needs %d VGPRs: below 2 waves/SIMD" % (n, v)
+
+
+def test_code_size_fits_instruction_cache_phases(isa):
+    text, _ = isa
+    lens = [int(x) for x in re.findall(r"; codeLenInByte = (\d+)", text)]
+    assert lens and max(lens) < 170_000, lens  # a second copy of the full-round body adds ~45 KB (measured -40 % speed)
+
+
+def test_one_multiply_add_per_product(isa):
+    """the digest kernel must execute (statically) far more signed 32x32+64 MADs than unsigned ones: when
+    LLVM sees through the digit masks it emits two v_mad_u64_u32 + two v_mov per product instead"""
+    text, _ = isa
+    start = text.index("_ZN4p2529k_merkle4")
+    body = text[start:text.index("s_endpgm", start)]
+    signed = body.count("v_mad_i64_i32")
+    unsigned = body.count("v_mad_u64_u32")
+    assert signed > 10_000 and unsigned < 0.1 * signed, (signed, unsigned)
+    assert body.count("v_mov_b32") < 0.10 * signed  # ~6 % today; the two-MAD lowering adds one move per product
+
+
+@pytest.mark.gpu
+def test_throughput_floor(gpu_ctx):
+    """loose floor (the kernel measures ~3.0e8 perm/s on MI355X): catches order-of-magnitude regressions only"""
+    import torch
+    n = 1 << 20
+    d_in = torch.randint(0, 2 ** 62, (n * 4, 4), dtype=torch.int64, device="cuda")
+    d_out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    import numpy as np
+    tag = np.arange(4, dtype=np.uint64)
+    for _ in range(2):
+        gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
+    e1.record()
+    torch.cuda.synchronize()
+    rate = 5 * n / (e0.elapsed_time(e1) * 1e-3)
+    assert rate > 1.5e8, rate
