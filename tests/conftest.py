@@ -13,6 +13,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_artefacts():
+    """fresh checkout: build libposeidon252_hip.so (hipcc cross-compiles gfx950 on a CPU-only host) and the
+    oracle once per session, exactly as __graft_entry__.build() does; a no-op when they are up to date"""
+    from poseidon252_amd import build as b
+    import oracle
+    if not os.path.exists(b.LIB) or not os.path.exists(oracle._LIB_PATH):
+        try:
+            b.build_library()
+        except Exception as e:  # GPU box without hipcc would still have the shipped .so; otherwise tests fail loudly later
+            print("build_library failed:", e)
+        try:
+            oracle.build()
+        except Exception as e:
+            print("oracle build failed:", e)
+    yield
+
+
 def _has_gpu():
     try:
         import torch
