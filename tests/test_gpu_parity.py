@@ -267,3 +267,25 @@ def test_tables_roundtrip_and_broadcast_equivalence(gpu_ctx):
     assert t.dtype == np.int32 and np.abs(t.astype(np.int64)).max() <= 1 << 28
     gpu_ctx.tables_import(t)
     assert np.array_equal(gpu_ctx.tables_export(), t)
+
+
+def test_adversarial_noncanonical_limbs_on_gpu(gpu_ctx, oracle_mod):
+    """same adversarial patterns as tests/test_host_arith.py, on the GPU, against the big-int model"""
+    import random
+    import pymodel
+    P = pymodel.P
+    C, M = pymodel.load_constants()
+    Rinv = pow(1 << 256, -1, P)
+    pats = [(1 << 256) - 1, (1 << 255) + 12345, P, P + 1, 2 * P - 1, int("55" * 32, 16), int("aa" * 32, 16),
+            sum(((1 << 29) - 1) << (29 * i) for i in range(8)) | (((1 << 24) - 1) << 232)]
+    rng = random.Random(4)
+    states = [[rng.choice(pats) for _ in range(5)] for _ in range(12)] + [[pats[0]] * 5]
+    st = np.array([[oracle_mod.int_to_limbs(v) for v in s] for s in states], dtype=np.uint64)
+    out = gpu_ctx.permute_batch(st)
+    for s, o in zip(states, out):
+        assert [oracle_mod.int_from_mont(x) for x in o] == pymodel.perm_reference([v * Rinv % P for v in s], C, M)
+    # sponge with a saturating tag and message: 9 inputs, 6 outputs
+    msg = st[:9, 0]
+    got = gpu_ctx.hash_batch(st[0, 1], msg[None], 9, 6)[0]
+    exp = pymodel.sponge(states[0][1] * Rinv % P, [s[0] * Rinv % P for s in states[:9]], 6, perm=lambda x: pymodel.perm_reference(x, C, M))
+    assert [oracle_mod.int_from_mont(x) for x in got] == exp

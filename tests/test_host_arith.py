@@ -147,3 +147,23 @@ def test_scaled_tables_match_bigint_derivation(oracle_mod, hosttest_lib):
     rng = random.Random(12)
     x = [rng.randrange(P) for _ in range(5)]
     assert pymodel.perm_scaled(x, C, M, S) == pymodel.perm_reference(x, C, M)
+
+
+def test_adversarial_noncanonical_limbs(oracle_mod, hosttest_lib):
+    """inputs the reference would never produce (limbs >= p, all-ones, digit-saturating patterns): the device
+    code treats the 256-bit pattern V as an integer, so the result must be the permutation of V * R^-1 mod p —
+    exercised to probe the column-bound / lazy-range arguments with the largest possible digits"""
+    C, M = pymodel.load_constants()
+    Rinv = pow(1 << 256, -1, P)
+    pats = [(1 << 256) - 1, (1 << 255) + 12345, P, P + 1, 2 * P - 1, 2 * P + 7, int("55" * 32, 16), int("aa" * 32, 16),
+            sum(((1 << 29) - 1) << (29 * i) for i in range(8)) | (((1 << 24) - 1) << 232), (1 << 256) - (1 << 200)]
+    rng = random.Random(4)
+    states = [[rng.choice(pats) for _ in range(5)] for _ in range(40)] + [[pats[0]] * 5, [pats[8]] * 5]
+    st = np.array([[oracle_mod.int_to_limbs(v) for v in s] for s in states], dtype=np.uint64)
+    out = np.empty_like(st)
+    for sched in (0, 1):
+        hosttest_lib.ht_permute29_sched(p(st), p(out), st.shape[0], sched)
+        for s, o in zip(states, out):
+            exp = pymodel.perm_reference([v * Rinv % P for v in s], C, M)
+            assert [oracle_mod.int_from_mont(x) for x in o] == exp
+            assert all(oracle_mod.lib().p252o_is_reduced(p(x)) for x in o)  # outputs are always canonical
