@@ -84,6 +84,11 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
 int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
                       uint64_t root[4], uint64_t* levels);
 size_t p252_merkle4_levels_len(size_t n_leaves);
+/* The same for arity 2: nodes are Hash::digest(Domain::Merkle2, [c0, c1]) (hash.rs:27-31), an odd level is
+ * padded with the zero scalar; `tag` must be the Merkle2 tag ([Absorb(2), Squeeze(1)], separator 0x3). */
+int p252_merkle2_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                      uint64_t root[4], uint64_t* levels);
+size_t p252_merkle2_levels_len(size_t n_leaves);
 
 /* Page-locked host memory (hipHostMalloc).  The host-buffer entry points pipeline H2D / kernel / D2H
  * over 3 streams for large batches; with buffers from p252_host_alloc the copies run at PCIe speed,
@@ -100,6 +105,8 @@ int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_i
                            size_t out_len, void* d_out, size_t n, void* hip_stream);
 /* d_levels may be NULL (context-owned scratch is used); d_root receives 1 scalar. */
 int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
+                             void* d_root, void* d_levels, void* hip_stream);
+int p252_merkle2_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
                              void* d_root, void* d_levels, void* hip_stream);
 int p252_sync(p252_ctx* ctx, void* hip_stream);
 

@@ -140,6 +140,25 @@ def merkle4_tree(tag, leaves, want_levels=False):
     return (root, levels, perms) if want_levels else (root, perms)
 
 
+def merkle2_tree(tag, leaves, want_levels=False):
+    tag = _c(tag).reshape(4)
+    leaves = _c(leaves).reshape(-1, 4)
+    n = leaves.shape[0]
+    total, c = 0, n
+    while c > 1:
+        c = (c + 1) // 2
+        total += c
+    root = np.empty(4, dtype=np.uint64)
+    levels = np.empty((total, 4), dtype=np.uint64) if want_levels else None
+    f = lib().p252o_merkle2_tree
+    f.argtypes = [_u64p, _u64p, ctypes.c_size_t, _u64p, _u64p]
+    f.restype = ctypes.c_longlong
+    perms = f(_p(tag), _p(leaves), n, _p(root), _p(levels) if want_levels else None)
+    if perms < 0:
+        raise ValueError("empty tree")
+    return (root, levels, perms) if want_levels else (root, perms)
+
+
 def merkle4_path_batch(tag, leaves, siblings, positions):
     tag = _c(tag).reshape(4)
     leaves = _c(leaves).reshape(-1, 4)

@@ -397,6 +397,40 @@ long long p252o_merkle4_tree(const uint64_t tag[4], const uint64_t *leaves, size
     return perms;
 }
 
+/* arity-2 tree over Domain::Merkle2 digests (hash.rs:27-31); same conventions as the arity-4 builder */
+long long p252o_merkle2_tree(const uint64_t tag[4], const uint64_t *leaves, size_t n_leaves,
+                             uint64_t root[4], uint64_t *levels) {
+    if (n_leaves == 0) return -1;
+    ensure_constants();
+    long long perms = 0;
+    size_t cur_n = n_leaves;
+    uint64_t *cur = (uint64_t *)malloc(n_leaves * 32);
+    memcpy(cur, leaves, n_leaves * 32);
+    uint64_t *lv_out = levels;
+    while (cur_n > 1) {
+        size_t next_n = (cur_n + 1) / 2;
+        uint64_t *next = (uint64_t *)malloc(next_n * 32);
+        for (size_t i = 0; i < next_n; ++i) {
+            uint64_t in[8];
+            memset(in, 0, sizeof in);
+            size_t have = cur_n - 2 * i < 2 ? cur_n - 2 * i : 2;
+            memcpy(in, cur + 8 * i, have * 32);
+            p252o_sponge(tag, in, 2, next + 4 * i, 1);
+            ++perms;
+        }
+        if (levels) {
+            memcpy(lv_out, next, next_n * 32);
+            lv_out += next_n * 4;
+        }
+        free(cur);
+        cur = next;
+        cur_n = next_n;
+    }
+    memcpy(root, cur, 32);
+    free(cur);
+    return perms;
+}
+
 /* Merkle opening: re-hash a branch.  children = the 3 siblings with the running value inserted at
  * slot positions[l]; node = digest(Merkle4, children) (hash.rs:22-26 composition). */
 int p252o_merkle4_path_batch(const uint64_t tag[4], const uint64_t *leaves, const uint64_t *siblings,

@@ -75,6 +75,10 @@ void p252o_kat_hash(const uint8_t *inputs_le32, size_t n, uint8_t out_le32[32]);
 long long p252o_merkle4_tree(const uint64_t tag[4], const uint64_t *leaves, size_t n_leaves,
                              uint64_t root[4], uint64_t *levels);
 
+/* arity-2 tree over Domain::Merkle2 digests (hash.rs:27-31): odd levels zero-padded, single leaf = root */
+long long p252o_merkle2_tree(const uint64_t tag[4], const uint64_t *leaves, size_t n_leaves,
+                             uint64_t root[4], uint64_t *levels);
+
 /* Merkle opening re-hash: leaves[n], siblings[n][depth][3], positions[n][depth] in 0..3 -> roots[n].
  * -1 on a position outside 0..3. */
 int p252o_merkle4_path_batch(const uint64_t tag[4], const uint64_t *leaves, const uint64_t *siblings,

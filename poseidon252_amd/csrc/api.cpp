@@ -166,25 +166,29 @@ int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_i
     hipStream_t st = (hipStream_t)hip_stream;
     if (in_len == 4 && out_len == 1)
         HIP_TRY(ctx, launch_merkle4(ctx->d_tab, tag_arg(tag), d_in, 4 * n, d_out, n, st));
+    else if (in_len == 2 && out_len == 1)  // Merkle2-shaped digests take the single-permutation kernel too
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, tag_arg(tag), d_in, 2 * n, d_out, n, st, 2));
     else
         HIP_TRY(ctx, launch_sponge(ctx->d_tab, tag_arg(tag), d_in, (unsigned)in_len, (unsigned)out_len, d_out, n, st));
     return P252_OK;
 }
 
-size_t p252_merkle4_levels_len(size_t n_leaves) {
+static size_t levels_len(size_t n_leaves, size_t arity) {
     size_t total = 0, c = n_leaves;
     while (c > 1) {
-        c = (c + 3) / 4;
+        c = (c + arity - 1) / arity;
         total += c;
     }
     return total;
 }
+size_t p252_merkle4_levels_len(size_t n_leaves) { return levels_len(n_leaves, 4); }
+size_t p252_merkle2_levels_len(size_t n_leaves) { return levels_len(n_leaves, 2); }
 
-int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
-                             void* d_root, void* d_levels, void* hip_stream) {
+static int merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
+                              void* d_root, void* d_levels, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
-    if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: n_leaves must be > 0");
-    if (!tag || !d_leaves || !d_root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: NULL buffer");
+    if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree: n_leaves must be > 0");
+    if (!tag || !d_leaves || !d_root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree: NULL buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     const TagArg t = tag_arg(tag);
@@ -192,17 +196,17 @@ int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
     size_t cur_n = n_leaves;
     char* lv = static_cast<char*>(d_levels);
     if (!d_levels) {  // ping-pong in context-owned scratch
-        const size_t l1 = (n_leaves + 3) / 4, l2 = (l1 + 3) / 4;
+        const size_t l1 = (n_leaves + arity - 1) / arity, l2 = (l1 + arity - 1) / arity;
         int rc = ensure(ctx, &ctx->d_lvl[0], &ctx->d_lvl_cap[0], l1 * 32);
         if (rc) return rc;
         rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], l2 * 32);
         if (rc) return rc;
     }
     int parity = 0;
-    while (cur_n > 1) {  // a single leaf is its own root: a 4^k-leaf tree costs exactly k levels
-        const size_t next_n = (cur_n + 3) / 4;
+    while (cur_n > 1) {  // a single leaf is its own root: an arity^k-leaf tree costs exactly k levels
+        const size_t next_n = (cur_n + arity - 1) / arity;
         char* next = d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]);
-        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st));
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, arity));
         cur = next;
         cur_n = next_n;
         if (d_levels) lv += next_n * 32;
@@ -210,6 +214,16 @@ int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
     }
     HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
     return P252_OK;
+}
+
+int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
+                             void* d_root, void* d_levels, void* hip_stream) {
+    return merkle_tree_device(ctx, 4, tag, d_leaves, n_leaves, d_root, d_levels, hip_stream);
+}
+
+int p252_merkle2_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
+                             void* d_root, void* d_levels, void* hip_stream) {
+    return merkle_tree_device(ctx, 2, tag, d_leaves, n_leaves, d_root, d_levels, hip_stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -307,14 +321,14 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
     return P252_OK;
 }
 
-int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
-                      uint64_t root[4], uint64_t* levels) {
+static int merkle_tree_host(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                            uint64_t root[4], uint64_t* levels) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
-    if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: n_leaves must be > 0");
-    if (!tag || !leaves || !root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_tree: NULL buffer");
+    if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree: n_leaves must be > 0");
+    if (!tag || !leaves || !root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree: NULL buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t leaf_bytes = n_leaves * 32;
-    const size_t lvl_bytes = p252_merkle4_levels_len(n_leaves) * 32;
+    const size_t lvl_bytes = levels_len(n_leaves, arity) * 32;
     int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, leaf_bytes);
     if (rc) return rc;
     rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, (levels ? lvl_bytes : 0) + 32);
@@ -322,11 +336,21 @@ int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leav
     HIP_TRY(ctx, hipMemcpy(ctx->d_in, leaves, leaf_bytes, hipMemcpyHostToDevice));
     char* d_root = static_cast<char*>(ctx->d_out);
     char* d_levels = levels ? d_root + 32 : nullptr;
-    rc = p252_merkle4_tree_device(ctx, tag, ctx->d_in, n_leaves, d_root, d_levels, nullptr);
+    rc = merkle_tree_device(ctx, arity, tag, ctx->d_in, n_leaves, d_root, d_levels, nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy(root, d_root, 32, hipMemcpyDeviceToHost));
-    if (levels) HIP_TRY(ctx, hipMemcpy(levels, d_levels, lvl_bytes, hipMemcpyDeviceToHost));
+    if (levels && lvl_bytes) HIP_TRY(ctx, hipMemcpy(levels, d_levels, lvl_bytes, hipMemcpyDeviceToHost));
     return P252_OK;
+}
+
+int p252_merkle4_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                      uint64_t root[4], uint64_t* levels) {
+    return merkle_tree_host(ctx, 4, tag, leaves, n_leaves, root, levels);
+}
+
+int p252_merkle2_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                      uint64_t root[4], uint64_t* levels) {
+    return merkle_tree_host(ctx, 2, tag, leaves, n_leaves, root, levels);
 }
 
 // page-locked host memory for callers that want the host-buffer entry points at PCIe speed

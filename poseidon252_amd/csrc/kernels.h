@@ -18,7 +18,7 @@ struct TagArg {
 
 hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t n, hipStream_t st);
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
-                          void* out, size_t n, hipStream_t st);
+                          void* out, size_t n, hipStream_t st, unsigned arity = 4);
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
                          unsigned out_len, void* out, size_t n, hipStream_t st);
 

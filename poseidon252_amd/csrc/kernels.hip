@@ -64,15 +64,17 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restric
 __global__ void __launch_bounds__(P252_BLOCK) k_merkle4(const int32_t* __restrict__ tab, TagArg tag,
                                                         const Scalar32* __restrict__ children,
                                                         size_t n_children, Scalar32* __restrict__ out,
-                                                        size_t n) {
+                                                        size_t n, unsigned arity) {
+    // arity 4: Domain::Merkle4 node; arity 2: Domain::Merkle2 node (hash.rs:27-31) — the same sponge with two
+    // absorbed elements, i.e. state [tag, c0, c1, 0, 0]; the caller passes the matching tag
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (idx >= n) return;
     E29 s[WIDTH];
     s[0] = from_mont4(tag.w);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const size_t c = idx * 4 + k;
-        if (c < n_children)
+        const size_t c = idx * arity + k;
+        if ((unsigned)k < arity && c < n_children)
             s[1 + k] = load_scalar(children + c);
         else
             s[1 + k] = e29_zero();
@@ -250,10 +252,10 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 }
 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
-                          void* out, size_t n, hipStream_t st) {
+                          void* out, size_t n, hipStream_t st, unsigned arity) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_merkle4, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
-                       static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n);
+                       static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity);
     return hipGetLastError();
 }
 

@@ -177,6 +177,18 @@ class Context:
                                                   levels.ctypes.data_as(_u64p) if want_levels else None))
         return (root, levels) if want_levels else root
 
+    def merkle2_tree(self, tag, leaves, want_levels=False):
+        """arity-2 tree over Hash::digest(Domain::Merkle2, [c0, c1]) nodes (hash.rs:27-31)"""
+        tag = _as_scalars(tag).reshape(4)
+        lv = _as_scalars(leaves).reshape(-1, 4)
+        n = lv.shape[0]
+        root = np.empty(4, dtype=np.uint64)
+        levels = np.empty((_lib.lib().p252_merkle2_levels_len(n), 4), dtype=np.uint64) if want_levels else None
+        self._check(_lib.lib().p252_merkle2_tree(self._h, tag.ctypes.data_as(_u64p), lv.ctypes.data_as(_u64p), n,
+                                                  root.ctypes.data_as(_u64p),
+                                                  levels.ctypes.data_as(_u64p) if want_levels else None))
+        return (root, levels) if want_levels else root
+
     # ---- device buffers (torch CUDA tensors; asynchronous on torch's current stream) ----
     @staticmethod
     def _stream():

@@ -31,7 +31,39 @@ def test_oracle_path_rejects_bad_position(oracle_mod):
         oracle_mod.merkle4_path_batch(z[0], z, np.zeros((1, 1, 3, 4), dtype=np.uint64), np.array([[4]], dtype=np.uint8))
 
 
+def test_oracle_merkle2_tree_is_composition_of_merkle2_digests(oracle_mod):
+    tag = oracle_mod.tag(1, [2], 1)  # Domain::Merkle2, [Absorb(2), Squeeze(1)], separator 0x3
+    lv = oracle_mod.fill_random(0x222, 5)  # 5 -> 3 (padded) -> 2 (padded) -> 1
+    root, levels, perms = oracle_mod.merkle2_tree(tag, lv, want_levels=True)
+    assert perms == 3 + 2 + 1 and levels.shape[0] == 6
+    pad = np.zeros((6, 4), dtype=np.uint64)
+    pad[:5] = lv
+    l1 = oracle_mod.hash_batch(tag, pad.reshape(3, 2, 4), 2, 1).reshape(3, 4)
+    assert np.array_equal(levels[:3], l1)
+    pad2 = np.zeros((4, 4), dtype=np.uint64)
+    pad2[:3] = l1
+    l2 = oracle_mod.hash_batch(tag, pad2.reshape(2, 2, 4), 2, 1).reshape(2, 4)
+    assert np.array_equal(root, oracle_mod.hash_batch(tag, l2.reshape(1, 2, 4), 2, 1).reshape(4))
+
+
 # ------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 33, 1000, 4097])
+def test_merkle2_tree_on_gpu(gpu_ctx, oracle_mod, n):
+    """Domain::Merkle2 (hash.rs:27-31): arity-2 tree, and Merkle2-shaped digests through hash_batch"""
+    import poseidon252_amd as P
+    tag = P.compute_tag(P.Domain.Merkle2, [2], 1)
+    lv = oracle_mod.fill_random(0x2000 + n, n)
+    root, levels = gpu_ctx.merkle2_tree(tag, lv, want_levels=True)
+    oroot, olevels, _ = oracle_mod.merkle2_tree(tag, lv, want_levels=True)
+    assert np.array_equal(root, oroot) and np.array_equal(levels, olevels)
+    assert np.array_equal(gpu_ctx.merkle2_tree(tag, lv), oroot)
+    if n >= 2:
+        pairs = lv[: 2 * (n // 2)].reshape(-1, 2, 4)
+        hb = P.HashBatch(P.Domain.Merkle2, 2, ctx=gpu_ctx)
+        assert np.array_equal(hb.digest(pairs), oracle_mod.hash_batch(tag, pairs, 2, 1))
+
+
 @pytest.mark.gpu
 def test_truncate250_device_matches_reference_rule(gpu_ctx, oracle_mod):
     import torch
