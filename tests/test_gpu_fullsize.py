@@ -83,6 +83,36 @@ def test_random_shapes_sweep(gpu_ctx, oracle_mod):
         assert np.array_equal(got, oracle_mod.hash_batch(tag, m, in_len, out_len)), (n, in_len, out_len)
 
 
+def test_two_threads_two_contexts(gpu_ctx, oracle_mod):
+    """ABI threading contract: distinct contexts are independent — two host threads hash concurrently
+    (ctypes releases the GIL), host-buffer path incl. the pipelined large-batch branch"""
+    import threading
+    import poseidon252_amd as P
+    tag = oracle_mod.tag(0, [4], 1)
+    data = [oracle_mod.fill_random(500 + t, 4 * 300000).reshape(300000, 4, 4) for t in range(2)]
+    results, errors = [None, None], []
+
+    def work(t):
+        try:
+            ctx = P.Context(0)
+            outs = [ctx.hash_batch(tag, data[t], 4, 1) for _ in range(3)]
+            assert all(np.array_equal(outs[0], o) for o in outs[1:])
+            results[t] = outs[0]
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(2):
+        idx = np.arange(0, 300000, 1501)
+        assert np.array_equal(results[t][idx], oracle_mod.hash_batch(tag, data[t][idx], 4, 1))
+
+
 def test_long_messages(gpu_ctx, oracle_mod):
     """few, very long messages: 1,025 and 4,099 scalars absorbed sequentially (257 / 1,025 permutations per lane)"""
     for n, in_len, out_len in [(3, 1025, 9), (2, 4099, 1)]:
