@@ -150,7 +150,7 @@ P252_HD void arma_exit(const E29 h[9], E29 s[WIDTH], TP tab) {
 //   v_q = sbox(u_q);   u_{q+1} = p_q + sum_{n=0..3} g_n v_{q-n}      (v_j = 0 for j < 1: zero history)
 // s[0..3] rotate so that s[0] is always the current projection.
 template <class TP>
-P252_HD void entry_round(E29 s[WIDTH], E29 h[9], TP tab) {
+P252_HD void entry_round(E29 s[WIDTH], E29 h[9], TP tab, int q) {
     typedef Tab29Layout Lay;
     h[7] = h[6];
     h[6] = h[5];
@@ -159,7 +159,8 @@ P252_HD void entry_round(E29 s[WIDTH], E29 h[9], TP tab) {
     A29 t;
     acc_set_hi(t, s[0]);
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc_mul(t, h[4 + n], tab + Lay::ENTRY_G + n * NL);
+    for (int n = 0; n < 4; ++n)
+        if (n < q) acc_mul(t, h[4 + n], tab + Lay::ENTRY_G + n * NL);  // v_{q-n} exists only for n < q (wave-uniform)
     const E29 unew = redc(t);
     h[3] = h[2];
     h[2] = h[1];
@@ -208,7 +209,7 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
                        f != RF - 1 && f != FULL_ROUNDS - 1);
             if (entry) h[0] = s[4];  // u_1
         } else if (step < STEP_ARMA0) {
-            entry_round(s, h, tab);
+            entry_round(s, h, tab, step - RF + 1);
         } else if (step < STEP_EXIT) {
 #pragma unroll
             for (int r = 0; r < ARMA_UNROLL; ++r) arma_round(h, tab, (step - STEP_ARMA0) * ARMA_UNROLL + r + 5);
