@@ -4,9 +4,10 @@
 // (src/hades/permutation/scalar.rs:39-64).  Two algebraically equivalent schedules, both producing
 // the reference's field elements (tables.hpp derives their constants):
 //   hades_permute_sparse  4 full | 60 sparse partial rounds (12 mults, 8 reductions each) | 4 full
-//   hades_permute         4 full (the 4th with the entry matrix) | 4 entry rounds (3+4 mults, 4 redc)
-//                         | 56 "ARMA" partial rounds (12 mults, 4 reductions each) | exit (32 mults,
-//                         4 reductions) | 4 full                                          <- kernels
+//   hades_permute         4 full (the 4th with the entry matrix) | 4 entry rounds (3 + <=4 mults, 4 redc)
+//                         | 56 "ARMA" partial rounds (3 + 8 mults, 4 reductions each) | exit (28 mults,
+//                         4 reductions) | 4 full; state re-scaled after every linear layer so that one
+//                         coefficient per row is the free constant tau (tables.hpp step 4)   <- kernels
 //
 // TP is any pointer-like giving int32 digits: tab[i].  In kernels it is a wave-uniform pointer so
 // the compiler keeps constants in SGPRs (s_load) and feeds them to v_mad_i64_i32 as scalar operands.
