@@ -80,7 +80,7 @@ static TagArg tag_arg(const uint64_t tag[4]) {
 
 extern "C" {
 
-const char* p252_version(void) { return "poseidon252_hip 0.1 (gfx950; 9x29-bit limbs; sparse partial rounds)"; }
+const char* p252_version(void) { return "poseidon252_hip 0.1 (gfx950; 9x29-bit limbs; re-scaled ARMA partial rounds)"; }
 
 int p252_device_count(void) {
     int n = 0;
