@@ -11,17 +11,17 @@
 #include "hades29.hpp"
 #include "kernels.h"
 
-// ARMA rounds per loop iteration, per kernel.  Measured on MI355X (42->5 sponge, 2^20 messages): unroll 1 / 2 / 4 =
-// 2.71e8 / 2.59e8 / 2.39e8 perm/s (code size and SGPR spills grow); the digest kernel k_merkle4 is the
-// opposite (2.78e8 / 2.79e8 / 2.85e8) and keeps the header default of 4.
+// ARMA rounds per loop iteration, per kernel.  Measured on MI355X with the re-scaled schedule (42->5 sponge,
+// 2^20 messages): unroll 1 / 2 / 4 = 2.80e8 / 2.92e8 / 2.41e8 perm/s (beyond 2 the code size and SGPR spills
+// win); the digest kernel k_merkle4 is flat from 4 to 8 (2.98e8) and keeps the header default of 4.
 #ifndef P252_UNROLL_PERMUTE
-#define P252_UNROLL_PERMUTE 1
+#define P252_UNROLL_PERMUTE 2
 #endif
 #ifndef P252_UNROLL_SPONGE
-#define P252_UNROLL_SPONGE 1
+#define P252_UNROLL_SPONGE 2
 #endif
 #ifndef P252_UNROLL_PATH
-#define P252_UNROLL_PATH 1
+#define P252_UNROLL_PATH 2
 #endif
 
 namespace p252 {
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_crypt(const int32_t* __restrict_
     const unsigned chunks = (len + 3) / 4;
 #pragma unroll 1
     for (unsigned it = 0; it <= chunks; ++it) {
-        hades_permute<0x1fu, 1>(s, tab);
+        hades_permute<0x1fu, P252_UNROLL_SPONGE>(s, tab);
         if (it < chunks) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
