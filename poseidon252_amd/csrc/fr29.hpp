@@ -150,8 +150,56 @@ P252_HD E29 redc(A29& t) {
         r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
-    r.d[NL - 1] = (int32_t)(t.c[2 * NL - 1] + carry);
+    r.d[NL - 1] = opaque_digit((int32_t)(t.c[2 * NL - 1] + carry));
     return r;
+}
+
+// ---- single-digit linear combinations (the integer MDS layer, hades29.hpp) ----
+// R29 holds sum_j n_j * X_j + kappa as nine 64-bit columns (n_j one digit, < 2^18 here).  row_redc1 does
+// ONE Montgomery digit step (subtract lo * p, drop the now-zero column) and the carry chain:
+// returns (T - lo p) / 2^29 in (T/2^29 - p, T/2^29].  8 + 9 per term instead of 72 + 81 per term.
+struct R29 {
+    int64_t c[NL];
+};
+template <class CP>
+P252_HD void row_set_c(R29& t, CP kappa) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) t.c[k] = kappa[k];
+}
+P252_HD void row_mac(R29& t, const E29& x, int32_t n) {
+    const int64_t nn = n;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) t.c[k] += (int64_t)x.d[k] * nn;
+}
+P252_HD E29 row_redc1(R29& t) {
+    const int64_t lo = opaque_digit((int32_t)((uint32_t)t.c[0] & DMASK));
+    t.c[1] += (t.c[0] >> WB) - lo * (int64_t)P252_P29_1;
+    t.c[2] -= lo * (int64_t)P252_P29_2;
+    t.c[3] -= lo * (int64_t)P252_P29_3;
+    t.c[4] -= lo * (int64_t)P252_P29_4;
+    t.c[5] -= lo * (int64_t)P252_P29_5;
+    t.c[6] -= lo * (int64_t)P252_P29_6;
+    t.c[7] -= lo * (int64_t)P252_P29_7;
+    t.c[8] -= lo * (int64_t)P252_P29_8;
+    E29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = t.c[1 + k] + carry;
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
+        carry = v >> WB;
+    }
+    r.d[NL - 1] = opaque_digit((int32_t)carry);
+    return r;
+}
+
+// x * n / R' for a 9-digit constant n (one generic Montgomery product)
+template <class CP>
+P252_HD E29 mul_c(const E29& x, CP n) {
+    A29 t;
+    acc_zero(t);
+    acc_mul(t, x, n);
+    return redc(t);
 }
 
 // carry-normalise an element whose digits have drifted (after digit-wise additions)

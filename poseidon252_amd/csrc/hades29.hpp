@@ -220,4 +220,52 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     }
 }
 
+// ---- schedule 3: integer MDS (tables.hpp step 5) ----
+// The MDS matrix is (R/L) * N with N[i][j] = L/(i+j+5) a one-digit integer, and x -> x^5 is homogeneous,
+// so the field factor travels in the scale of the stored state and every round is
+//     X_j = sbox(Z_j)  (all lanes / lane 4 only; in partial rounds lane 4 is then multiplied by G_k — the
+//                       one generic product of the round — so that all five X_j carry the same scale)
+//     Z'_i = (sum_j N_ij X_j + kappa_i) / 2^29          45 one-digit MACs + 1 Montgomery digit step per lane
+// A full round is 15 + 0 generic products (reference: 15 + 25), a partial round 3 + 1 (reference: 3 + 25).
+// One multiplication by F per output lane restores the reference's Montgomery scale at the end.
+// n = &h[i] for output lane i (N is a Hankel matrix: N[i][j] = h[i+j], nine distinct values).
+template <class TP>
+P252_HD E29 int_row(const E29 x[WIDTH], TP n, TP kappa) {
+    R29 t;
+    row_set_c(t, kappa);
+#pragma unroll
+    for (int j = 0; j < WIDTH; ++j) row_mac(t, x[j], n[j]);
+    return row_redc1(t);
+}
+
+template <unsigned OUT_ROWS = 0x1fu, class TP>
+P252_HD void hades_permute_int(E29 s[WIDTH], TP tab) {
+    typedef Tab29Layout Lay;
+    constexpr int RF = FULL_ROUNDS / 2;
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
+#pragma unroll 1
+    for (int k = 0; k < ROUNDS; ++k) {
+        const bool full = k < RF || k >= RF + PARTIAL_ROUNDS;  // wave-uniform
+        E29 x[WIDTH];
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = sbox(s[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = s[j];
+        }
+        x[4] = sbox(s[4]);
+        if (!full) x[4] = mul_c(x[4], tab + Lay::INT_G + (k - RF) * NL);
+        // all five lanes in every round, the last one included: skipping unused lanes there would save 0.3 % and
+        // cost a branch per lane (the products must stay in one basic block with their operands' sign extensions,
+        // or instruction selection falls back to 64 x 64-bit multiplies)
+#pragma unroll
+        for (int i = 0; i < WIDTH; ++i) s[i] = int_row(x, tab + Lay::INT_N + i, tab + Lay::INT_KAPPA + (k * WIDTH + i) * NL);
+    }
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i)
+        if ((OUT_ROWS >> i) & 1u) s[i] = mul_c(s[i], tab + Lay::INT_F);
+}
+
 }  // namespace p252

@@ -102,7 +102,7 @@ void ht_sbox29(const uint64_t* a, uint64_t* out, size_t n) {
     }
 }
 
-// schedule: 0 = ARMA (what the kernels run), 1 = all-sparse
+// schedule: 0 = ARMA, 1 = all-sparse, 2 = integer MDS
 void ht_permute29_sched(const uint64_t* states, uint64_t* out, size_t n, int schedule) {
     const int32_t* tab = tab29().data();
     for (size_t i = 0; i < n; ++i) {
@@ -110,6 +110,8 @@ void ht_permute29_sched(const uint64_t* states, uint64_t* out, size_t n, int sch
         for (int k = 0; k < WIDTH; ++k) s[k] = from_mont4(reinterpret_cast<const uint32_t*>(states + (i * 5 + k) * 4));
         if (schedule == 0)
             hades_permute(s, tab);
+        else if (schedule == 2)
+            hades_permute_int(s, tab);
         else
             hades_permute_sparse(s, tab);
         for (int k = 0; k < WIDTH; ++k) to_mont4(s[k], reinterpret_cast<uint32_t*>(out + (i * 5 + k) * 4));
@@ -120,5 +122,19 @@ void ht_permute29(const uint64_t* states, uint64_t* out, size_t n) { ht_permute2
 // Static worst-case |column| of every lazy accumulation in the schedules, assuming state digits
 // < 2^29 (top digit < 2^24) and using the ACTUAL table constants; includes the < 2^61 the
 // reduction itself adds.  Must stay below 2^63 (tests/test_host_arith.py).
+// integer-MDS constants as Montgomery-limb words of the raw residues: kappa[68][5], G[60], F; returns count, or 0
+// when mds.bin does not have the Cauchy structure
+size_t ht_tables_int_raw(uint64_t* out) {
+    HadesTables T;
+    derive_tables(ARC_BIN, MDS_BIN, T);
+    if (!T.int_ok) return 0;
+    size_t k = 0;
+    auto put = [&](const FrHost& v) { v.to_canonical(out + 4 * k++); };
+    for (int r = 0; r < ROUNDS; ++r) for (int i = 0; i < 5; ++i) put(T.int_kappa[r][i]);
+    for (int q = 0; q < PARTIAL_ROUNDS; ++q) put(T.int_g[q]);
+    put(T.int_f);
+    return k;
+}
+
 double ht_max_column_bound29() { return max_column_bound29(tab29().data()); }
 }

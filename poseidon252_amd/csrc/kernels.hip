@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restric
     E29 s[WIDTH];
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) s[k] = load_scalar(in + idx * WIDTH + k);
-    hades_permute<0x1fu, P252_UNROLL_PERMUTE>(s, tab);
+    hades_permute_int<0x1fu>(s, tab);
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) store_scalar(out + idx * WIDTH + k, s[k]);
 }
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4(const int32_t* __restric
         else
             s[1 + k] = e29_zero();
     }
-    hades_permute<0x02u>(s, tab);  // only lane 1 is squeezed
+    hades_permute_int<0x02u>(s, tab);  // only lane 1 is squeezed
     store_scalar(out + idx, s[1]);
 }
 
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
         if ((unsigned)k < in_len) s[1 + k] = load_scalar(my_in + k);
 #pragma unroll 1
     for (unsigned it = 1; it < absorb_blocks + squeeze_blocks; ++it) {
-        hades_permute<0x1fu, P252_UNROLL_SPONGE>(s, tab);
+        hades_permute_int<0x1fu>(s, tab);
         if (it < absorb_blocks) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_crypt(const int32_t* __restrict_
     const unsigned chunks = (len + 3) / 4;
 #pragma unroll 1
     for (unsigned it = 0; it <= chunks; ++it) {
-        hades_permute<0x1fu, P252_UNROLL_SPONGE>(s, tab);
+        hades_permute_int<0x1fu>(s, tab);
         if (it < chunks) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path(const int32_t* __re
             s[3].d[k] = p == 2 ? cur.d[k] : (p < 2 ? b.d[k] : c.d[k]);
             s[4].d[k] = p == 3 ? cur.d[k] : c.d[k];
         }
-        hades_permute<0x02u, P252_UNROLL_PATH>(s, tab);
+        hades_permute_int<0x02u>(s, tab);
         cur = s[1];
     }
     store_scalar(roots + idx, cur);

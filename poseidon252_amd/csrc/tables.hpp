@@ -62,7 +62,16 @@ struct HadesTables {
     FrHost sc_mats[FULL_ROUNDS][WIDTH][WIDTH];
     FrHost sc_adds[FULL_ROUNDS][WIDTH];
     FrHost lam;                       // time-invariant scale of the partial phase: beta_3 * lam^4 == tau
+    // ---- integer-MDS schedule (derive_tables step 5): residues exactly as the device holds them ----
+    FrHost int_kappa[ROUNDS][WIDTH];  // added (at the low end of the row accumulator) by the linear layer of round k
+    FrHost int_g[PARTIAL_ROUNDS];     // G_k: equalises the scale of the lane-4 S-box output in partial round k
+    FrHost int_f;                     // F: restores the Montgomery scale R after round 67
+    bool int_ok;                      // mds.bin really is R/(i+j+5) (the structure this schedule rests on)
 };
+
+// The MDS matrix is R/(i+j+5) (mds_matrix.rs:21-36 reads Montgomery words of 1/(i+j+5) with from_raw):
+// INT_L/(i+j+5) is an integer below 2^17 for every entry.
+constexpr int32_t INT_L = 360360;  // lcm(5..13)
 
 inline uint64_t u64_from_buffer(const unsigned char* buf, size_t i) {  // src/hades.rs:40-51
     uint64_t v = 0;
@@ -333,6 +342,38 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
         }
         for (int i = 0; i < WIDTH; ++i) L[i] = Ln[i];
     }
+
+    // ---- (5) integer-MDS schedule.  M = (R/L) N with N[i][j] = L/(i+j+5) a one-digit integer, so the linear
+    // layer costs 9 MACs per term; the field factor R/L lives in the scale s_k of the stored state
+    // (stored = s_k * true S-box input, the same s_k on all five lanes), which x -> x^5 turns into s_k^5:
+    //   full round     X_j = Z_j^5 / R'^4                                   scale e = s^5 / R'^4
+    //   partial round  X_j = Z_j (j<4), X_4 = Z_4^5/R'^4 * G_k/R'           G_k = R'^5 / s^4  =>  e = s
+    //   linear layer   Z'_i = (sum_j N_ij X_j + kappa_i) / 2^29             s' = e L / (R 2^29),
+    //                                                                       kappa_i = 2^29 s' C_{k+1}[i]
+    //   after round 67 out_i R = Z'_i F / R',  F = R R' / s_68.     tests/pymodel.py::derive_int is the twin.
+    {
+        T.int_ok = true;
+        for (int i = 0; i < WIDTH; ++i)
+            for (int j = 0; j < WIDTH; ++j)  // a different mds.bin must not pass silently
+                if (!(M[i][j] * FrHost::from_u64((uint64_t)(i + j + 5)) == FrHost::pow2(256))) T.int_ok = false;
+        const FrHost RP = FrHost::pow2(261), RM = FrHost::pow2(256), T29 = FrHost::pow2(29);
+        const FrHost RP4inv = ((RP * RP) * (RP * RP)).inv(), RP5 = (RP * RP) * (RP * RP) * RP;
+        const FrHost step = FrHost::from_u64((uint64_t)INT_L) * RM.inv() * T29.inv();
+        FrHost s = RM;
+        for (int k = 0; k < ROUNDS; ++k) {
+            const bool full = k < RF || k >= RF + PARTIAL_ROUNDS;
+            FrHost e;
+            if (full) {
+                e = s.pow5() * RP4inv;
+            } else {
+                T.int_g[k - RF] = ((s * s) * (s * s)).inv() * RP5;
+                e = s;
+            }
+            s = e * step;
+            for (int i = 0; i < WIDTH; ++i) T.int_kappa[k][i] = k + 1 < ROUNDS ? T29 * s * C[k + 1][i] : FrHost::zero();
+        }
+        T.int_f = RM * RP * s.inv();
+    }
 }
 
 // =============================================================================================
@@ -362,7 +403,12 @@ struct Tab29Layout {
     static constexpr int SC_MATS = EXIT_ADD + 4 * NL;                         // [8][5][5][9] MS  per-round matrices
     static constexpr int SC_ADDS = SC_MATS + FULL_ROUNDS * WIDTH * WIDTH * NL;  // [8][5][9] A
     static constexpr int ENTRY_G = SC_ADDS + FULL_ROUNDS * WIDTH * NL;        // [4][9] MS  (g_0..g_3, scaled)
-    static constexpr int TOTAL = ENTRY_G + 4 * NL;
+    // integer-MDS schedule: raw residues (digits encode the value itself)
+    static constexpr int INT_N = ENTRY_G + 4 * NL;                            // [9] one int each: N[i][j] = h[i+j], h[d] = L/(d+5)
+    static constexpr int INT_KAPPA = INT_N + NL;                              // [68][5][9]
+    static constexpr int INT_G = INT_KAPPA + ROUNDS * WIDTH * NL;             // [60][9]
+    static constexpr int INT_F = INT_G + PARTIAL_ROUNDS * NL;                 // [9]
+    static constexpr int TOTAL = INT_F + NL;
 };
 
 inline void encode_balanced29(const FrHost& field_value, int32_t out[NL]) {
@@ -437,6 +483,12 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
             put(Lay::SC_ADDS + (f * WIDTH + i) * NL, T.sc_adds[f][i], fA);
         }
     for (int n = 0; n < 4; ++n) put(Lay::ENTRY_G + n * NL, T.entry_g[n], fMS);
+    const FrHost one = FrHost::one();
+    for (int d = 0; d < 2 * WIDTH - 1; ++d) tab[Lay::INT_N + d] = INT_L / (d + 5);
+    for (int k = 0; k < ROUNDS; ++k)
+        for (int i = 0; i < WIDTH; ++i) put(Lay::INT_KAPPA + (k * WIDTH + i) * NL, T.int_kappa[k][i], one);
+    for (int q = 0; q < PARTIAL_ROUNDS; ++q) put(Lay::INT_G + q * NL, T.int_g[q], one);
+    put(Lay::INT_F, T.int_f, one);
     return tab;
 }
 
@@ -478,6 +530,14 @@ inline double max_column_bound29(const int32_t* tab) {
         group({Lay::EXIT_GY + (i * 4 + 0) * NL, Lay::EXIT_GY + (i * 4 + 1) * NL, Lay::EXIT_GY + (i * 4 + 2) * NL,
                Lay::EXIT_GY + (i * 4 + 3) * NL, Lay::EXIT_GV + (i * 4 + 0) * NL, Lay::EXIT_GV + (i * 4 + 1) * NL,
                Lay::EXIT_GV + (i * 4 + 2) * NL, Lay::EXIT_GV + (i * 4 + 3) * NL});
+    for (int q = 0; q < PARTIAL_ROUNDS; ++q) group({Lay::INT_G + q * NL});
+    group({Lay::INT_F});
+    {  // integer rows: nine columns, five one-digit terms + kappa, then one digit step
+        double nsum = 0;
+        for (int j = 0; j < WIDTH; ++j) nsum += (double)tab[Lay::INT_N + j];  // row 0 is the largest
+        const double row = DIG * nsum + 268435456.0 /* kappa digit */ + DIG * (double)P252_P29_1 + 68719476736.0;
+        if (row > worst) worst = row;
+    }
     // S-box: element x element (9 products of 2^29 x 2^29) and squarings (<= 4.5 * 2^59)
     const double sbox_col = 9.0 * DIG * DIG + REDC;
     if (sbox_col > worst) worst = sbox_col;

@@ -420,3 +420,68 @@ def perm_scaled(x, C=None, M=None, S=None):
     for f in range(4, 8):
         y = [(a + b) % P for a, b in zip(matvec(S["mats"][f], [pow(t, 5, P) for t in y]), S["adds"][f])]
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# Schedule 4 — "integer MDS": the schedule the kernels execute (tables.hpp step 5, hades29.hpp)
+#
+# The MDS matrix is a Cauchy matrix in disguise: mds.bin holds M[i][j] = R/(i+j+5) mod p with R = 2^256
+# (mds_matrix.rs:21-36 reads Montgomery words with from_raw).  So M = (R/L) * N with the INTEGER matrix
+# N[i][j] = L/(i+j+5), L = lcm(5..13) = 360360, every entry < 2^17: a product by N[i][j] is 9 MACs
+# (one digit) instead of 81, and the constant field factor R/L is carried in the *scale* of the stored
+# state, which costs nothing because x -> x^5 is homogeneous:
+#     stored Z = s_k * y   (y = true S-box input of round k, one scale s_k for all five lanes)
+#     full round:     X_j = Z_j^5 / R'^4                       (3 Montgomery products, R' = 2^261)
+#     partial round:  X_j = Z_j (j < 4),  X_4 = Z_4^5 / R'^4 * G_k / R'   with G_k = s_k^-4 R'^5, so
+#                     that all five X_j carry the same scale (the one generic product of the round)
+#     linear layer:   Z'_i = (sum_j N[i][j] X_j + kappa_i) / 2^29    — ONE Montgomery digit step —
+#                     with s_{k+1} = e_k L / (R 2^29),  kappa_i = 2^29 s_{k+1} C_{k+1}[i]
+#     after round 67: out_i * R = Z'_i * F / R',  F = R R' / s_68
+# Everything below works on residues mod p exactly as the device does (digit-level effects — lazy
+# residues, signed top digits — are covered by the C++ host build in test_host_arith.py).
+# ------------------------------------------------------------------------------------------------
+L_INT = 360360
+N_INT = [[L_INT // (i + j + 5) for j in range(5)] for i in range(5)]
+RP = pow(2, 261, P)   # R'
+RM = pow(2, 256, P)   # R (Montgomery radix of BlsScalar)
+
+
+def derive_int(C, M):
+    assert all(M[i][j] == RM * pow(i + j + 5, -1, P) % P for i in range(5) for j in range(5))
+    inv = lambda v: pow(v, -1, P)
+    Rf = FULL // 2
+    s = RM  # Z = in*R + C_0*R
+    out = dict(c_first=[c * RM % P for c in C[0]], kappa=[], G={}, scales=[s])
+    for k in range(ROUNDS):
+        full = k < Rf or k >= Rf + PARTIAL
+        if full:
+            e = pow(s, 5, P) * inv(pow(RP, 4, P)) % P
+        else:
+            out["G"][k] = inv(pow(s, 4, P)) * pow(RP, 5, P) % P
+            e = s
+        s = e * L_INT % P * inv(RM) % P * inv(pow(2, 29, P)) % P
+        out["scales"].append(s)
+        out["kappa"].append([pow(2, 29, P) * s % P * C[k + 1][i] % P for i in range(5)] if k + 1 < ROUNDS else [0] * 5)
+    out["F"] = RM * RP % P * inv(s) % P
+    return out
+
+
+def perm_int(x_mont, C=None, M=None, T=None):
+    """x_mont: the five input residues in BlsScalar Montgomery form (x*R); returns out*R residues"""
+    if C is None:
+        C, M = load_constants()
+    if T is None:
+        T = derive_int(C, M)
+    inv = lambda v: pow(v, -1, P)
+    iRP, i29 = inv(RP), inv(pow(2, 29, P))
+    mm = lambda a, b: a * b % P * iRP % P  # one Montgomery product (redc)
+    sbox = lambda z: mm(mm(mm(z, z), mm(z, z)), z)
+    Rf = FULL // 2
+    Z = [(x_mont[i] + T["c_first"][i]) % P for i in range(5)]
+    for k in range(ROUNDS):
+        if k < Rf or k >= Rf + PARTIAL:
+            X = [sbox(z) for z in Z]
+        else:
+            X = Z[:4] + [mm(sbox(Z[4]), T["G"][k])]
+        Z = [(sum(N_INT[i][j] * X[j] for j in range(5)) + T["kappa"][k][i]) * i29 % P for i in range(5)]
+    return [mm(z, T["F"]) for z in Z]
