@@ -171,9 +171,48 @@ P252_HD void row_mac(R29& t, const E29& x, int32_t n) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) t.c[k] += (int64_t)x.d[k] * nn;
 }
+// The value 1 in a form the optimiser cannot see through: (int64)carry * one + column is then ONE
+// v_mad_i64_i32 (4 cycles) instead of a sign extension plus a 64-bit add (2 + 4), and the carry itself
+// is a v_alignbit_b32 (2 cycles) instead of a 64-bit shift (4).  Row columns stay below 2^59, so their
+// carries fit 32 bits (the full redc's columns reach 2^62.5: it keeps 64-bit carries).
+P252_HD int32_t opaque_one() {
+    int32_t one = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(one));
+#endif
+    return one;
+}
+#define P252_ROW_STEP(k, PK)                                                                  \
+    {                                                                                         \
+        const int64_t v = t.c[k] - lo * (int64_t)(PK) + (int64_t)carry * one;                 \
+        r.d[(k) - 1] = opaque_digit((int32_t)((uint32_t)v & DMASK));                          \
+        carry = (int32_t)(v >> WB);                                                           \
+    }
 P252_HD E29 row_redc1(R29& t) {
+    const int64_t one = opaque_one();
     const int64_t lo = opaque_digit((int32_t)((uint32_t)t.c[0] & DMASK));
-    t.c[1] += (t.c[0] >> WB) - lo * (int64_t)P252_P29_1;
+    int32_t carry = (int32_t)(t.c[0] >> WB);
+    E29 r;
+    P252_ROW_STEP(1, P252_P29_1)
+    P252_ROW_STEP(2, P252_P29_2)
+    P252_ROW_STEP(3, P252_P29_3)
+    P252_ROW_STEP(4, P252_P29_4)
+    P252_ROW_STEP(5, P252_P29_5)
+    P252_ROW_STEP(6, P252_P29_6)
+    P252_ROW_STEP(7, P252_P29_7)
+    P252_ROW_STEP(8, P252_P29_8)
+    r.d[NL - 1] = opaque_digit(carry);
+    return r;
+}
+#undef P252_ROW_STEP
+
+// Same value, digits NOT carried through: d_k = (column_k mod 2^29) + floor(column_{k-1} / 2^29), so
+// |d_k| < 2^30.1 instead of [0, 2^29).  Good enough for a lane that only feeds the next integer layer
+// (products with one-digit integers: |column| < 2^18.1 * 2^30.1 + 2^58, carries stay < 2^29.4 — a fixed
+// point, not a drift); such a lane must be normalize()d before it enters an S-box.  6 cycles per digit, no chain.
+P252_HD E29 row_redc1_lazy(R29& t) {
+    const int64_t lo = opaque_digit((int32_t)((uint32_t)t.c[0] & DMASK));
+    t.c[1] -= lo * (int64_t)P252_P29_1;
     t.c[2] -= lo * (int64_t)P252_P29_2;
     t.c[3] -= lo * (int64_t)P252_P29_3;
     t.c[4] -= lo * (int64_t)P252_P29_4;
@@ -182,14 +221,10 @@ P252_HD E29 row_redc1(R29& t) {
     t.c[7] -= lo * (int64_t)P252_P29_7;
     t.c[8] -= lo * (int64_t)P252_P29_8;
     E29 r;
-    int64_t carry = 0;
 #pragma unroll
-    for (int k = 0; k < NL - 1; ++k) {
-        const int64_t v = t.c[1 + k] + carry;
-        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
-        carry = v >> WB;
-    }
-    r.d[NL - 1] = opaque_digit((int32_t)carry);
+    for (int k = 0; k < NL - 1; ++k)
+        r.d[k] = opaque_digit((int32_t)((uint32_t)t.c[1 + k] & DMASK) + (int32_t)(t.c[k] >> WB));
+    r.d[NL - 1] = opaque_digit((int32_t)(t.c[NL - 1] >> WB));
     return r;
 }
 

@@ -1,13 +1,14 @@
 // hades29.hpp — the Hades permutation on E29 lazy residues (one state per lane).
 //
 // Replaces Hades::perm (src/hades/permutation.rs:105-123) with its ARC / S-box / MDS steps
-// (src/hades/permutation/scalar.rs:39-64).  Two algebraically equivalent schedules, both producing
+// (src/hades/permutation/scalar.rs:39-64).  Three algebraically equivalent schedules, all producing
 // the reference's field elements (tables.hpp derives their constants):
-//   hades_permute_sparse  4 full | 60 sparse partial rounds (12 mults, 8 reductions each) | 4 full
-//   hades_permute         4 full (the 4th with the entry matrix) | 4 entry rounds (3 + <=4 mults, 4 redc)
-//                         | 56 "ARMA" partial rounds (3 + 8 mults, 4 reductions each) | exit (28 mults,
-//                         4 reductions) | 4 full; state re-scaled after every linear layer so that one
-//                         coefficient per row is the free constant tau (tables.hpp step 4)   <- kernels
+//   hades_permute_sparse  4 full | 60 sparse partial rounds (12 generic products, 8 reductions each) | 4 full
+//   hades_permute_int     integer MDS in all 68 rounds: 25 one-digit products per linear layer, one generic
+//                         product per partial round
+//   hades_permute         integer MDS in the full rounds, integer ARMA recurrence in the partial rounds
+//                         (nine one-digit products + one generic product per partial round)      <- kernels
+// The first two are kept as independent cross-checks (tests/test_host_arith.py runs all three on the host).
 //
 // TP is any pointer-like giving int32 digits: tab[i].  In kernels it is a wave-uniform pointer so
 // the compiler keeps constants in SGPRs (s_load) and feeds them to v_mad_i64_i32 as scalar operands.
@@ -21,26 +22,19 @@
 
 namespace p252 {
 
-// One full round: state <- Mat * sbox(state) + add     (ARC of this round was folded into the
-// previous layer's `add`).  5 S-boxes (15 mults, 15 redc) + 25 products + 5 redc.
-// ROWS < 5 computes only the first ROWS output lanes (the last round of a digest needs lane 1 only).
-// unit0: column 0 of `mat` is the constant tau (scaled schedule) — its 5 products are plain additions.
+// One full round of the sparse schedule: state <- Mat * sbox(state) + add   (ARC of this round was folded
+// into the previous layer's `add`).  5 S-boxes (15 mults, 15 redc) + 25 generic products + 5 redc.
 template <class TP>
-P252_HD void full_round(E29 s[WIDTH], TP mat, TP add, unsigned rows = 0x1fu, bool unit0 = false) {
+P252_HD void full_round(E29 s[WIDTH], TP mat, TP add) {
     E29 v[WIDTH];
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) v[i] = sbox(s[i]);
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) {
-        if (!((rows >> k) & 1u)) continue;  // wave-uniform
         A29 t;
         acc_set_hi_c(t, add + k * NL);
-        if (unit0)  // wave-uniform
-            acc_add_hi(t, v[0]);
-        else
-            acc_mul(t, v[0], mat + (k * WIDTH) * NL);
 #pragma unroll
-        for (int j = 1; j < WIDTH; ++j) acc_mul(t, v[j], mat + (k * WIDTH + j) * NL);  // MDS[k][j] * state[j]
+        for (int j = 0; j < WIDTH; ++j) acc_mul(t, v[j], mat + (k * WIDTH + j) * NL);  // MDS[k][j] * state[j]
         s[k] = redc(t);
     }
 }
@@ -92,135 +86,7 @@ P252_HD void hades_permute_sparse(E29 s[WIDTH], TP tab) {
     }
 }
 
-// ---- schedule 2: ARMA partial rounds ----
-// History layout while in the ARMA phase (q = index of the partial round about to run, 5..60):
-//   h[0..3] = u_q, u_{q-1}, u_{q-2}, u_{q-3}      (S-box inputs, constants included)
-//   h[4..8] = v_{q-1}, v_{q-2}, v_{q-3}, v_{q-4}, (free)   -> after the S-box: v_q .. v_{q-4}
-// One step:  v_q = sbox(u_q);  u_{q+1} = sum a_m u_{q+1-m} + sum beta_n v_{q-n} + kappa_{q+1}.
-template <class TP>
-P252_HD void arma_round(E29 h[9], TP tab, int q) {
-    typedef Tab29Layout Lay;
-    // shift v history, newest first
-    h[8] = h[7];
-    h[7] = h[6];
-    h[6] = h[5];
-    h[5] = h[4];
-    h[4] = sbox(h[0]);
-    A29 t;
-    acc_set_hi_c(t, tab + Lay::ARMA_KAPPA + (q + 1 - 6) * NL);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc_mul(t, h[m], tab + Lay::ARMA_A + m * NL);
-#pragma unroll
-    for (int n = 0; n < 5; ++n) {
-        if (n == 3)
-            acc_add_hi(t, h[4 + n]);  // scaled schedule: beta_3 * lam^4 == tau, the free constant
-        else
-            acc_mul(t, h[4 + n], tab + Lay::ARMA_BETA + n * NL);
-    }
-    const E29 unew = redc(t);
-    h[3] = h[2];
-    h[2] = h[1];
-    h[1] = h[0];
-    h[0] = unew;
-}
-
-// After round 60: h[0..3] = u_61..u_58, h[4..7] = v_60..v_57.  Recover lanes 0..3 of the state
-// (closing constants included); lane 4 = u_61.
-template <class TP>
-P252_HD void arma_exit(const E29 h[9], E29 s[WIDTH], TP tab) {
-    typedef Tab29Layout Lay;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        A29 t;
-        acc_set_hi_c(t, tab + Lay::EXIT_ADD + i * NL);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {  // Gy[i][r] multiplies u_{58+r} = h[3-r]; Gv[i][r] multiplies v_{57+r} = h[7-r]
-            acc_mul(t, h[3 - r], tab + Lay::EXIT_GY + (i * 4 + r) * NL);
-            if (r == 3)
-                acc_add_hi(t, h[7 - r]);  // scaled schedule: the coefficient of v_60 is tau in every row
-            else
-                acc_mul(t, h[7 - r], tab + Lay::EXIT_GV + (i * 4 + r) * NL);
-        }
-        s[i] = redc(t);
-    }
-    s[4] = h[0];
-}
-
-// Entry rounds q = 1..4 of the partial phase.  Full round 3 (matrix MDS_ENTRY) has left the projections
-// p_q = c^T A^(q-1) L_1 + k_{q+1} in s[0..3] and u_1 in h[0]; then
-//   v_q = sbox(u_q);   u_{q+1} = p_q + sum_{n=0..3} g_n v_{q-n}      (v_j = 0 for j < 1: zero history)
-// s[0..3] rotate so that s[0] is always the current projection.
-template <class TP>
-P252_HD void entry_round(E29 s[WIDTH], E29 h[9], TP tab, int q) {
-    typedef Tab29Layout Lay;
-    h[7] = h[6];
-    h[6] = h[5];
-    h[5] = h[4];
-    h[4] = sbox(h[0]);
-    A29 t;
-    acc_set_hi(t, s[0]);
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-        if (n < q) acc_mul(t, h[4 + n], tab + Lay::ENTRY_G + n * NL);  // v_{q-n} exists only for n < q (wave-uniform)
-    const E29 unew = redc(t);
-    h[3] = h[2];
-    h[2] = h[1];
-    h[1] = h[0];
-    h[0] = unew;
-    s[0] = s[1];
-    s[1] = s[2];
-    s[2] = s[3];
-}
-
-// One loop with a wave-uniform phase switch, so each large unrolled body exists once in the
-// instruction stream.  Phases (step): 0-3 full (3 = entry matrix) | 4-7 entry q=1..4 | 8-63 ARMA
-// q=5..60 | 64 exit | 65-68 full.  OUT_ROWS: bit k set = lane k of the result is needed (a Merkle4
-// digest needs lane 1 only, so the last round computes 1 of its 5 rows).
-template <unsigned OUT_ROWS = 0x1fu, int ARMA_UNROLL_T = P252_ARMA_UNROLL, class TP>
-P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
-    typedef Tab29Layout Lay;
-    constexpr int RF = FULL_ROUNDS / 2;
-    constexpr int N_ENTRY = 4;
-    constexpr int STEP_ARMA0 = RF + N_ENTRY;                           // 8
-    constexpr int ARMA_UNROLL = ARMA_UNROLL_T;  // ARMA rounds per loop step (history shifts become renames)
-    static_assert((PARTIAL_ROUNDS - N_ENTRY) % ARMA_UNROLL == 0, "56 ARMA rounds must split evenly");
-    constexpr int STEP_EXIT = STEP_ARMA0 + (PARTIAL_ROUNDS - N_ENTRY) / ARMA_UNROLL;
-    constexpr int STEP_END = STEP_EXIT + 1 + RF;                       // 69
-#pragma unroll
-    for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
-    E29 h[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) h[i] = e29_zero();
-    // the row mask of the last round must look like a run-time value: with a visible constant the
-    // compiler peels the last iteration and emits a SECOND copy of the 50 KB full-round body
-    // (measured: 136 KB code, I-cache thrash, 2.7e8 -> 1.7e8 perm/s)
-    unsigned last_rows = OUT_ROWS;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(last_rows));
-#endif
-#pragma unroll 1
-    for (int step = 0; step < STEP_END; ++step) {
-        if (step < RF || step > STEP_EXIT) {
-            const bool entry = step == RF - 1;
-            const int f = step < RF ? step : step - STEP_EXIT - 1 + RF;
-            const unsigned rows = step == STEP_END - 1 ? last_rows : 0x1fu;
-            // scaled schedule: one matrix per round; column 0 is the free constant except in the entry
-            // round (f = 3) and in the last round (f = 7, which must output the true state)
-            full_round(s, tab + Lay::SC_MATS + f * WIDTH * WIDTH * NL, tab + Lay::SC_ADDS + f * WIDTH * NL, rows,
-                       f != RF - 1 && f != FULL_ROUNDS - 1);
-            if (entry) h[0] = s[4];  // u_1
-        } else if (step < STEP_ARMA0) {
-            entry_round(s, h, tab, step - RF + 1);
-        } else if (step < STEP_EXIT) {
-#pragma unroll
-            for (int r = 0; r < ARMA_UNROLL; ++r) arma_round(h, tab, (step - STEP_ARMA0) * ARMA_UNROLL + r + 5);
-        } else {
-            arma_exit(h, s, tab);
-        }
-    }
-}
-
-// ---- schedule 3: integer MDS (tables.hpp step 5) ----
+// ---- schedule 2: integer MDS in all rounds (tables.hpp (B)) ----
 // The MDS matrix is (R/L) * N with N[i][j] = L/(i+j+5) a one-digit integer, and x -> x^5 is homogeneous,
 // so the field factor travels in the scale of the stored state and every round is
 //     X_j = sbox(Z_j)  (all lanes / lane 4 only; in partial rounds lane 4 is then multiplied by G_k — the
@@ -229,15 +95,20 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
 // A full round is 15 + 0 generic products (reference: 15 + 25), a partial round 3 + 1 (reference: 3 + 25).
 // One multiplication by F per output lane restores the reference's Montgomery scale at the end.
 // n = &h[i] for output lane i (N is a Hankel matrix: N[i][j] = h[i+j], nine distinct values).
-template <class TP>
+// LAZY: leave the digits un-carried (row_redc1_lazy) — for lanes that feed only the next integer layer.
+template <bool LAZY = false, class TP>
 P252_HD E29 int_row(const E29 x[WIDTH], TP n, TP kappa) {
     R29 t;
     row_set_c(t, kappa);
 #pragma unroll
     for (int j = 0; j < WIDTH; ++j) row_mac(t, x[j], n[j]);
-    return row_redc1(t);
+    return LAZY ? row_redc1_lazy(t) : row_redc1(t);
 }
 
+// All five lanes are computed in every round, the last one included: skipping the unused lanes of a digest
+// there would save 0.3 % and cost a branch per lane, and the products must stay in ONE basic block with their
+// operands' sign extensions (instruction selection works per block: a sign extension hoisted out of it turns
+// v_mad_i64_i32 into a 64 x 64-bit multiply emulation).
 template <unsigned OUT_ROWS = 0x1fu, class TP>
 P252_HD void hades_permute_int(E29 s[WIDTH], TP tab) {
     typedef Tab29Layout Lay;
@@ -246,26 +117,167 @@ P252_HD void hades_permute_int(E29 s[WIDTH], TP tab) {
     for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
 #pragma unroll 1
     for (int k = 0; k < ROUNDS; ++k) {
-        const bool full = k < RF || k >= RF + PARTIAL_ROUNDS;  // wave-uniform
+        const TP kap = tab + Lay::INT_KAPPA + k * WIDTH * NL;
         E29 x[WIDTH];
-        if (full) {
+        if (k < RF || k >= RF + PARTIAL_ROUNDS) {  // wave-uniform
+            if (k == RF + PARTIAL_ROUNDS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = sbox(s[j]);
+                for (int j = 0; j < 4; ++j) normalize(s[j]);  // lanes 0..3 leave the partial rounds un-carried
+            }
+#pragma unroll
+            for (int j = 0; j < WIDTH; ++j) x[j] = sbox(s[j]);
+#pragma unroll
+            for (int i = 0; i < WIDTH; ++i) s[i] = int_row(x, tab + Lay::INT_N + i, kap + i * NL);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = s[j];
-        }
-        x[4] = sbox(s[4]);
-        if (!full) x[4] = mul_c(x[4], tab + Lay::INT_G + (k - RF) * NL);
-        // all five lanes in every round, the last one included: skipping unused lanes there would save 0.3 % and
-        // cost a branch per lane (the products must stay in one basic block with their operands' sign extensions,
-        // or instruction selection falls back to 64 x 64-bit multiplies)
+            x[4] = mul_c(sbox(s[4]), tab + Lay::INT_G + (k - RF) * NL);
 #pragma unroll
-        for (int i = 0; i < WIDTH; ++i) s[i] = int_row(x, tab + Lay::INT_N + i, tab + Lay::INT_KAPPA + (k * WIDTH + i) * NL);
+            for (int i = 0; i < 4; ++i) s[i] = int_row<true>(x, tab + Lay::INT_N + i, kap + i * NL);
+            s[4] = int_row(x, tab + Lay::INT_N + 4, kap + 4 * NL);
+        }
     }
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i)
         if ((OUT_ROWS >> i) & 1u) s[i] = mul_c(s[i], tab + Lay::INT_F);
+}
+
+// ---- schedule 3: integer MDS in the full rounds + integer ARMA recurrence in the partial rounds (tables.hpp (C)) ----
+// History while in the partial phase (q = index of the partial round about to run, 1..60):
+//   U[0..3] = U_q, U_{q-1}, U_{q-2}, U_{q-3}          (scaled S-box inputs)
+//   W[0..4] = W_{q-1} .. W_{q-5}                        -> after the S-box: W_q .. W_{q-4}
+// One step:  W_q = sbox(U_q) * G_q / R';
+//   U_{q+1} = ( sum_m A_m U_{q+1-m} 2^(29(5-m)) + sum_n B_n W_{q-n} 2^(29(4-n)) ) / 2^145 + K_{q+1}
+// A term of age j sits j digits lower, so the nine one-digit products land in columns 0..12, five Montgomery
+// digit steps clear columns 0..4, and K (nine digits) is simply preloaded into columns 5..13.
+// ab = A_1..A_4, B_0..B_4 (ints); kg = K_{q+1}[9], G_q[9].
+template <class TP>
+P252_HD void ai_round(E29 U[4], E29 W[5], TP ab, TP kg) {
+    W[4] = W[3];
+    W[3] = W[2];
+    W[2] = W[1];
+    W[1] = W[0];
+    W[0] = mul_c(sbox(U[0]), kg + NL);
+    int64_t c[NL + 5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c[k] = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) c[5 + k] = kg[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // base column 4 - j: A_{j+1} U_{q-j} and B_j W_{q-j}
+        const int64_t aj = ab[j], bj = ab[4 + j];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) c[4 - j + k] += (int64_t)U[j].d[k] * aj + (int64_t)W[j].d[k] * bj;
+    }
+    {
+        const int64_t b4 = ab[8];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) c[k] += (int64_t)W[4].d[k] * b4;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int64_t lo = opaque_digit((int32_t)((uint32_t)c[i] & DMASK));
+        c[i + 1] += (c[i] >> WB) - lo * (int64_t)P252_P29_1;
+        c[i + 2] -= lo * (int64_t)P252_P29_2;
+        c[i + 3] -= lo * (int64_t)P252_P29_3;
+        c[i + 4] -= lo * (int64_t)P252_P29_4;
+        c[i + 5] -= lo * (int64_t)P252_P29_5;
+        c[i + 6] -= lo * (int64_t)P252_P29_6;
+        c[i + 7] -= lo * (int64_t)P252_P29_7;
+        c[i + 8] -= lo * (int64_t)P252_P29_8;
+    }
+    E29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = c[5 + k] + carry;
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
+        carry = v >> WB;
+    }
+    r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 4] + carry));
+    U[3] = U[2];
+    U[2] = U[1];
+    U[1] = U[0];
+    U[0] = r;
+}
+
+// sum_t x_t * mul_t / R' + add: a generic row (entry and exit of the partial phase)
+template <int TERMS, class TP>
+P252_HD E29 gen_row(const E29* const x[TERMS], const TP mul[TERMS], TP add) {
+    A29 t;
+    acc_set_hi_c(t, add);
+#pragma unroll
+    for (int j = 0; j < TERMS; ++j) acc_mul(t, *x[j], mul[j]);
+    return redc(t);
+}
+
+// One loop with a wave-uniform phase switch, so each large unrolled body exists once in the instruction
+// stream.  Steps: 0-3 full (3 = entry: lanes 0..3 of its linear layer are the generic rows of the virtual history)
+// | 60/UNROLL ARMA steps | exit | 4 full.  OUT_ROWS: bit k set = lane k of the result is needed (a Merkle4
+// digest needs lane 1 only: the multiplication by F is done for that lane alone).
+template <unsigned OUT_ROWS = 0x1fu, int ARMA_UNROLL_T = P252_ARMA_UNROLL, class TP>
+P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
+    typedef Tab29Layout Lay;
+    constexpr int RF = FULL_ROUNDS / 2;
+    constexpr int UR = ARMA_UNROLL_T;  // ARMA rounds per loop step (history shifts become renames)
+    static_assert(PARTIAL_ROUNDS % UR == 0, "60 ARMA rounds must split evenly");
+    constexpr int STEP_EXIT = RF + PARTIAL_ROUNDS / UR;
+    constexpr int STEP_END = STEP_EXIT + 1 + RF;
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
+    E29 U[4], W[5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) U[i] = e29_zero();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) W[i] = e29_zero();
+#pragma unroll 1
+    for (int step = 0; step < STEP_END; ++step) {
+        if (step < RF || step > STEP_EXIT) {
+            const int f = step < RF ? step : step - STEP_EXIT - 1 + RF;
+            const TP kap = tab + Lay::AI_KAPPA + f * WIDTH * NL;
+            E29 x[WIDTH];
+#pragma unroll
+            for (int j = 0; j < WIDTH; ++j) x[j] = sbox(s[j]);
+            if (f == RF - 1) {
+                const E29* const xs[WIDTH] = {&x[0], &x[1], &x[2], &x[3], &x[4]};
+                E29 th[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const TP mul[WIDTH] = {tab + Lay::AI_ENT_MUL + (i * WIDTH + 0) * NL, tab + Lay::AI_ENT_MUL + (i * WIDTH + 1) * NL,
+                                           tab + Lay::AI_ENT_MUL + (i * WIDTH + 2) * NL, tab + Lay::AI_ENT_MUL + (i * WIDTH + 3) * NL,
+                                           tab + Lay::AI_ENT_MUL + (i * WIDTH + 4) * NL};
+                    th[i] = gen_row<WIDTH>(xs, mul, tab + Lay::AI_ENT_ADD + i * NL);
+                }
+                U[0] = int_row(x, tab + Lay::INT_N + 4, kap + 4 * NL);  // U_1
+                U[1] = th[0];                                           // U_0, U_-1, U_-2: virtual
+                U[2] = th[1];
+                U[3] = th[2];
+                W[0] = th[3];                                           // W_0: virtual; W_-1.. = 0
+            } else {
+#pragma unroll
+                for (int i = 0; i < WIDTH; ++i) s[i] = int_row(x, tab + Lay::INT_N + i, kap + i * NL);
+            }
+        } else if (step < STEP_EXIT) {
+#pragma unroll
+            for (int r = 0; r < UR; ++r)
+                ai_round(U, W, tab + Lay::AI_AB, tab + Lay::AI_KG + ((step - RF) * UR + r) * 2 * NL);
+        } else {
+            // after round 60: U[0..3] = U_61..U_58, W[0..3] = W_60..W_57
+            const E29* const hs[8] = {&U[3], &U[2], &U[1], &U[0], &W[3], &W[2], &W[1], &W[0]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const TP mul[8] = {tab + Lay::AI_EX_GY + (i * 4 + 0) * NL, tab + Lay::AI_EX_GY + (i * 4 + 1) * NL,
+                                   tab + Lay::AI_EX_GY + (i * 4 + 2) * NL, tab + Lay::AI_EX_GY + (i * 4 + 3) * NL,
+                                   tab + Lay::AI_EX_GV + (i * 4 + 0) * NL, tab + Lay::AI_EX_GV + (i * 4 + 1) * NL,
+                                   tab + Lay::AI_EX_GV + (i * 4 + 2) * NL, tab + Lay::AI_EX_GV + (i * 4 + 3) * NL};
+                s[i] = gen_row<8>(hs, mul, tab + Lay::AI_EX_ADD + i * NL);
+            }
+            s[4] = U[0];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WIDTH; ++i)
+        if ((OUT_ROWS >> i) & 1u) s[i] = mul_c(s[i], tab + Lay::AI_F);
 }
 
 }  // namespace p252

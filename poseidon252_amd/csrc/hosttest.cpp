@@ -45,23 +45,22 @@ size_t ht_tables_raw(uint64_t* out) {
     return k;
 }
 
-// scaled-schedule constants as Montgomery limbs (for comparison with tests/pymodel.py::derive_scaled):
-//  lam, sc_mats[8][25], sc_adds[8][5], entry_g[4], arma_a[4], arma_beta[5], arma_kappa[56], exit_gy[16], exit_gv[16], exit_add[4]
-size_t ht_tables_scaled_raw(uint64_t* out) {
+// integer-ARMA constants (residues, canonical words): ai_kappa[8][5], ent_mul[4][5], ent_add[4], then per round
+// q = 1..60: K_{q+1}, G_q; ex_gy[16], ex_gv[16], ex_add[4], F.  Returns the count, or 0 when mds.bin lacks the structure.
+size_t ht_tables_armaint_raw(uint64_t* out) {
     HadesTables T;
     derive_tables(ARC_BIN, MDS_BIN, T);
+    if (!T.int_ok) return 0;
     size_t k = 0;
-    auto put = [&](const FrHost& v) { std::memcpy(out + 4 * k++, v.l, 32); };
-    put(T.lam);
-    for (int f = 0; f < 8; ++f) for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) put(T.sc_mats[f][i][j]);
-    for (int f = 0; f < 8; ++f) for (int i = 0; i < 5; ++i) put(T.sc_adds[f][i]);
-    for (int n = 0; n < 4; ++n) put(T.entry_g[n]);
-    for (int m = 0; m < 4; ++m) put(T.arma_a[m]);
-    for (int n = 0; n < 5; ++n) put(T.arma_beta[n]);
-    for (int q = 0; q < 56; ++q) put(T.arma_kappa[q]);
-    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.exit_gy[i][r]);
-    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.exit_gv[i][r]);
-    for (int i = 0; i < 4; ++i) put(T.exit_add[i]);
+    auto put = [&](const FrHost& v) { v.to_canonical(out + 4 * k++); };
+    for (int f = 0; f < 8; ++f) for (int i = 0; i < 5; ++i) put(T.ai_kappa[f][i]);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) put(T.ai_ent_mul[i][j]);
+    for (int i = 0; i < 4; ++i) put(T.ai_ent_add[i]);
+    for (int q = 0; q < 60; ++q) { put(T.ai_k[q]); put(T.ai_g[q]); }
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.ai_ex_gy[i][r]);
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.ai_ex_gv[i][r]);
+    for (int i = 0; i < 4; ++i) put(T.ai_ex_add[i]);
+    put(T.ai_f);
     return k;
 }
 
@@ -102,7 +101,7 @@ void ht_sbox29(const uint64_t* a, uint64_t* out, size_t n) {
     }
 }
 
-// schedule: 0 = ARMA, 1 = all-sparse, 2 = integer MDS
+// schedule: 0 = integer ARMA (what the kernels run), 1 = all-sparse, 2 = integer MDS in all rounds
 void ht_permute29_sched(const uint64_t* states, uint64_t* out, size_t n, int schedule) {
     const int32_t* tab = tab29().data();
     for (size_t i = 0; i < n; ++i) {

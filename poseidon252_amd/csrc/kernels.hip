@@ -14,6 +14,10 @@
 // ARMA rounds per loop iteration, per kernel.  Measured on MI355X with the re-scaled schedule (42->5 sponge,
 // 2^20 messages): unroll 1 / 2 / 4 = 2.80e8 / 2.92e8 / 2.41e8 perm/s (beyond 2 the code size and SGPR spills
 // win); the digest kernel k_merkle4 is flat from 4 to 8 (2.98e8) and keeps the header default of 4.
+// developer switch for occupancy experiments: -DP252_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
+#ifndef P252_WAVES_ATTR
+#define P252_WAVES_ATTR
+#endif
 #ifndef P252_UNROLL_PERMUTE
 #define P252_UNROLL_PERMUTE 2
 #endif
@@ -53,7 +57,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restric
     E29 s[WIDTH];
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) s[k] = load_scalar(in + idx * WIDTH + k);
-    hades_permute_int<0x1fu>(s, tab);
+    hades_permute<0x1fu>(s, tab);
 #pragma unroll
     for (int k = 0; k < WIDTH; ++k) store_scalar(out + idx * WIDTH + k, s[k]);
 }
@@ -61,7 +65,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restric
 // ---- Merkle4 digest: Hash::digest(Domain::Merkle4, [c0..c3]) = perm([tag, c0, c1, c2, c3])[1]
 // (hash.rs:128-155 with io-pattern [Absorb(4), Squeeze(1)]).  `n_children` may be short of 4*n:
 // missing children are the zero scalar (hash.rs:22-26). ----
-__global__ void __launch_bounds__(P252_BLOCK) k_merkle4(const int32_t* __restrict__ tab, TagArg tag,
+__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4(const int32_t* __restrict__ tab, TagArg tag,
                                                         const Scalar32* __restrict__ children,
                                                         size_t n_children, Scalar32* __restrict__ out,
                                                         size_t n, unsigned arity) {
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4(const int32_t* __restric
         else
             s[1 + k] = e29_zero();
     }
-    hades_permute_int<0x02u>(s, tab);  // only lane 1 is squeezed
+    hades_permute<0x02u>(s, tab);  // only lane 1 is squeezed
     store_scalar(out + idx, s[1]);
 }
 
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
         if ((unsigned)k < in_len) s[1 + k] = load_scalar(my_in + k);
 #pragma unroll 1
     for (unsigned it = 1; it < absorb_blocks + squeeze_blocks; ++it) {
-        hades_permute_int<0x1fu>(s, tab);
+        hades_permute<0x1fu>(s, tab);
         if (it < absorb_blocks) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -148,7 +152,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_crypt(const int32_t* __restrict_
     const unsigned chunks = (len + 3) / 4;
 #pragma unroll 1
     for (unsigned it = 0; it <= chunks; ++it) {
-        hades_permute_int<0x1fu>(s, tab);
+        hades_permute<0x1fu>(s, tab);
         if (it < chunks) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path(const int32_t* __re
             s[3].d[k] = p == 2 ? cur.d[k] : (p < 2 ? b.d[k] : c.d[k]);
             s[4].d[k] = p == 3 ? cur.d[k] : c.d[k];
         }
-        hades_permute_int<0x02u>(s, tab);
+        hades_permute<0x02u>(s, tab);
         cur = s[1];
     }
     store_scalar(roots + idx, cur);

@@ -4,15 +4,17 @@
 // src/hades/round_constants.rs:26-54 and src/hades/mds_matrix.rs:17-39 read them
 // (u64_from_buffer little-endian, BlsScalar::from_raw => field value = that integer mod p).
 //
-// Output: the constants of an algebraically equivalent schedule of Hades::perm
+// Output: the constants of three algebraically equivalent schedules of Hades::perm
 // (src/hades/permutation.rs:105-123) — same field elements out, hence bit-identical limbs:
-//   * round constants of the 60 partial rounds pushed forward through the linear layer so that
-//     each partial round adds ONE constant (to lane 4, before its S-box);
-//   * the MDS matrix of the partial rounds factored M = M'' * M' (M' commutes with the lane-4
-//     S-box, M'' is identity except row 4 / column 4): 9 multiplications per partial round
-//     instead of 25, plus one dense pre-matrix merged into full round 3.
-// Field-multiplication count per permutation: 8*40 + 60*12 = 1040 (reference schedule: 2000).
-// tests/pymodel.py holds an independent big-int derivation; tests/test_tables.py compares.
+//   (A) "sparse": partial-round constants pushed forward, MDS of the partial rounds factored into sparse
+//       matrices (9 generic products per partial round instead of 25).  Host cross-check only.
+//   (B) "integer MDS": mds.bin is R/(i+j+5), i.e. (R/L) times the INTEGER matrix N[i][j] = L/(i+j+5) (L = 360360,
+//       entries < 2^17); x -> x^5 is homogeneous, so the field factor travels in the scale of the stored
+//       state and every linear layer is 25 one-digit products.  Host cross-check only.
+//   (C) "integer ARMA": (B) in the full rounds; the 60 partial rounds as the 4th-order linear recurrence
+//       u_{q+1} = sum a_m u_{q+1-m} + sum beta_n v_{q-n} + kappa_{q+1}, whose coefficients are one-digit
+//       integers after geometric re-scaling.  This is what the kernels run.
+// tests/pymodel.py holds independent big-int derivations of all three; tests/test_host_arith.py compares.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -27,6 +29,15 @@ constexpr int FULL_ROUNDS = 8;      // src/hades.rs:29
 constexpr int PARTIAL_ROUNDS = 60;  // src/hades.rs:31
 constexpr int ROUNDS = FULL_ROUNDS + PARTIAL_ROUNDS;
 
+// mds.bin[i][j] = R/(i+j+5) (mds_matrix.rs:21-36 reads Montgomery words of 1/(i+j+5) with from_raw):
+constexpr int32_t INT_L = 360360;  // lcm(5..13): INT_L/(i+j+5) is an integer below 2^17 for every entry
+// The rational recurrence coefficients a~_m, b~_n of the Cauchy system become integers below 2^25 as
+// A_m = a~_m D^m and B_n = b~_n D^n K  (tests/pymodel.py::_rational_arma derives them with exact fractions;
+// derive_tables checks them against the field values computed from mds.bin).
+constexpr int32_t INT_D = 27720, INT_K = 12870;
+constexpr int32_t ARMA_A_INT[4] = {15104, -4729406, 18244864, -419265};
+constexpr int32_t ARMA_B_INT[5] = {990, -1555121, 23296324, -2924911, 1694};
+
 struct SparseRound {
     FrHost w[4];    // row 4 of M''_q, columns 0..3
     FrHost d;       // M''_q[4][4]
@@ -35,43 +46,34 @@ struct SparseRound {
 };
 
 struct HadesTables {
-    FrHost c_first[WIDTH];            // ARC of round 0
+    // ---- (A) sparse schedule: field VALUES ----
+    FrHost c_first[WIDTH];                // ARC of round 0
     FrHost full_add[FULL_ROUNDS][WIDTH];  // vector added after the matrix of full round f (f = 0..7)
-    FrHost mds[WIDTH][WIDTH];         // M
-    FrHost mds_pre[WIDTH][WIDTH];     // M'_1 * M, used by full round index 3
+    FrHost mds[WIDTH][WIDTH];             // M
+    FrHost mds_pre[WIDTH][WIDTH];         // M'_1 * M, used by full round index 3
     SparseRound sparse[PARTIAL_ROUNDS];
-    FrHost last_add[4];               // lanes 0..3 after the last sparse layer
-    // ---- "ARMA" form of partial rounds 5..60 (see derive_tables) ----
-    FrHost arma_a[4];                 // a_1..a_4: A^4 = a1 A^3 + a2 A^2 + a3 A + a4 I
-    FrHost arma_beta[5];              // beta_0..beta_4
-    FrHost arma_kappa[PARTIAL_ROUNDS - 4];  // kappa_6 .. kappa_61  (index q-6)
-    FrHost exit_gy[4][4];             // L_61 = Gy (u_58..u_61) + Gv (v_57..v_60) + exit_add
+    FrHost last_add[4];                   // lanes 0..3 after the last sparse layer
+    // ---- the partial rounds as a linear system (true field values; shared by the tests) ----
+    FrHost arma_a[4];                     // a_1..a_4: A^4 = a1 A^3 + a2 A^2 + a3 A + a4 I
+    FrHost arma_beta[5];                  // beta_0..beta_4
+    FrHost exit_gy[4][4];                 // lanes 0..3 after round 60 = Gy (u_58..u_61) + Gv (v_57..v_60) + const
     FrHost exit_gv[4][4];
-    FrHost exit_add[4];
-    // ---- direct entry into the ARMA phase: full round 3 outputs the projections p_q = c^T A^(q-1) L_1
-    //      (rows 0..3) and u_1 (row 4); then u_{q+1} = p_q + sum_{n<q} g_n v_{q-n}  for q = 1..4 ----
-    FrHost mds_entry[WIDTH][WIDTH];   // rows 0..3: (c^T A^(q-1)) * M[0..3][:], row 4: M[4][:]   (unscaled)
-    FrHost entry_add[WIDTH];          // k_2, k_3, k_4, k_5, k_1                                  (unscaled)
-    FrHost entry_g[4];                // Markov parameters g_0..g_3 (scaled by lam^4, see below)
-    // ---- state re-scaling (x^5 is homogeneous: a diagonal scaling commutes with an S-box layer up to 5th
-    //      powers).  After every linear layer the state is re-scaled so that ONE coefficient per output row
-    //      equals tau = 2^-20, the value whose device encoding is exactly 2^261: that product becomes a
-    //      plain addition.  arma_beta / arma_kappa / exit_* / entry_g above hold the SCALED values;
-    //      sc_mats / sc_adds are the per-round matrices and additive constants of the 8 full rounds
-    //      (index 3 = the entry matrix).  Column 0 of rounds 0,1,2,4,5,6 is tau. ----
-    FrHost sc_mats[FULL_ROUNDS][WIDTH][WIDTH];
-    FrHost sc_adds[FULL_ROUNDS][WIDTH];
-    FrHost lam;                       // time-invariant scale of the partial phase: beta_3 * lam^4 == tau
-    // ---- integer-MDS schedule (derive_tables step 5): residues exactly as the device holds them ----
-    FrHost int_kappa[ROUNDS][WIDTH];  // added (at the low end of the row accumulator) by the linear layer of round k
-    FrHost int_g[PARTIAL_ROUNDS];     // G_k: equalises the scale of the lane-4 S-box output in partial round k
-    FrHost int_f;                     // F: restores the Montgomery scale R after round 67
-    bool int_ok;                      // mds.bin really is R/(i+j+5) (the structure this schedule rests on)
+    // ---- (B) integer MDS, all 68 rounds: RESIDUES exactly as the device holds them ----
+    FrHost int_kappa[ROUNDS][WIDTH];      // added (at the low end of the row accumulator) by the linear layer of round k
+    FrHost int_g[PARTIAL_ROUNDS];         // G_k: equalises the scale of the lane-4 S-box output in partial round k
+    FrHost int_f;                         // F: restores the Montgomery scale R after round 67
+    bool int_ok;                          // mds.bin really is R/(i+j+5), and ARMA_*_INT match it
+    // ---- (C) integer ARMA: residues as the device holds them ----
+    FrHost ai_kappa[FULL_ROUNDS][WIDTH];  // integer rows of the full rounds f = 0..7 (f = 3: lane 4 only)
+    FrHost ai_ent_mul[4][WIDTH];          // entry: virtual history (U_0, U_-1, U_-2, W_0) = generic rows of round 3's S-box outputs
+    FrHost ai_ent_add[4];
+    FrHost ai_k[PARTIAL_ROUNDS];          // K_{q+1} at [q-1], q = 1..60
+    FrHost ai_g[PARTIAL_ROUNDS];          // G_q at [q-1]
+    FrHost ai_ex_gy[4][4];                // exit rows: multipliers of U_58..U_61
+    FrHost ai_ex_gv[4][4];                //            multipliers of W_57..W_60
+    FrHost ai_ex_add[4];
+    FrHost ai_f;
 };
-
-// The MDS matrix is R/(i+j+5) (mds_matrix.rs:21-36 reads Montgomery words of 1/(i+j+5) with from_raw):
-// INT_L/(i+j+5) is an integer below 2^17 for every entry.
-constexpr int32_t INT_L = 360360;  // lcm(5..13)
 
 inline uint64_t u64_from_buffer(const unsigned char* buf, size_t i) {  // src/hades.rs:40-51
     uint64_t v = 0;
@@ -107,6 +109,13 @@ inline void mat4_inverse(const FrHost A[4][4], FrHost out[4][4]) {
         for (int j = 0; j < 4; ++j) out[i][j] = a[i][4 + j];
 }
 
+inline FrHost fr_from_i64(int64_t v) { return v < 0 ? FrHost::from_u64((uint64_t)(-v)).neg() : FrHost::from_u64((uint64_t)v); }
+inline FrHost fr_pow_u(const FrHost& b, unsigned e) {
+    FrHost r = FrHost::one();
+    for (unsigned i = 0; i < e; ++i) r = r * b;
+    return r;
+}
+
 inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds_bin, HadesTables& T) {
     FrHost C[ROUNDS][WIDTH];
     for (int j = 0; j < ROUNDS * WIDTH; ++j) {  // round_constants.rs:40-51
@@ -122,7 +131,8 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
             M[i][j] = FrHost::from_raw(raw);
         }
     const int RF = FULL_ROUNDS / 2;
-    // ---- (1) forward-push the partial-round constants ----
+    // ================= (A) sparse schedule =================
+    // ---- forward-push the partial-round constants ----
     FrHost k_const[PARTIAL_ROUNDS];
     FrHost delta[WIDTH];
     for (int i = 0; i < WIDTH; ++i) delta[i] = FrHost::zero();
@@ -138,7 +148,7 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
     }
     FrHost closing_first[WIDTH];
     for (int i = 0; i < WIDTH; ++i) closing_first[i] = C[RF + PARTIAL_ROUNDS][i] + delta[i];
-    // ---- (2) sparse factorisation, last partial round first ----
+    // ---- sparse factorisation, last partial round first ----
     FrHost Mk[WIDTH][WIDTH];
     for (int i = 0; i < WIDTH; ++i)
         for (int j = 0; j < WIDTH; ++j) Mk[i][j] = M[i][j];
@@ -183,12 +193,11 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
     for (int f = RF; f < FULL_ROUNDS - 1; ++f)  // closing rounds: round index f + PARTIAL
         for (int i = 0; i < WIDTH; ++i) T.full_add[f][i] = C[f + PARTIAL_ROUNDS + 1][i];
 
-    // ---- (3) ARMA form.  With M = [[A, b], [c^T, d]] the partial rounds are the 4th-order LTI system
-    //   L_{q+1} = A L_q + b v_q,   u_{q+1} = c^T L_q + d v_q + k_{q+1}   (u = S-box input, v = u^5).
-    // Cayley-Hamilton on A eliminates L:  u_{q+1} = sum a_m u_{q+1-m} + sum beta_n v_{q-n} + kappa_{q+1}
-    // for q >= 5: 9 multiplications and ONE reduction per partial round.  Rounds 1..4 run in the sparse
-    // form (they create the history); the state lanes 0..3 are recovered after round 60 through the
-    // observability matrix.  tests/pymodel.py::derive_arma is the independent big-int derivation.
+    // ================= the partial rounds as a linear system =================
+    // With M = [[A, b], [c^T, d]]:  x_{q+1} = A x_q + b v_q + const,  u_{q+1} = c^T x_q + d v_q + const
+    // (x = lanes 0..3, u = S-box input of lane 4, v = u^5).  Cayley-Hamilton on A eliminates x:
+    //   u_{q+1} = sum a_m u_{q+1-m} + sum beta_n v_{q-n} + kappa_{q+1};
+    // the lanes 0..3 are recovered from the history through the observability matrix (exit_gy / exit_gv).
     FrHost A[4][4], bvec[4], cvec[4];
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < 4; ++j) A[i][j] = M[i][j];
@@ -238,14 +247,6 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
         for (int m = 1; m <= 4 && m <= n; ++m) acc = acc - T.arma_a[m - 1] * g[n - m];
         T.arma_beta[n] = acc;
     }
-    FrHost kq[PARTIAL_ROUNDS + 2];  // k_1..k_60, k_61 := closing constant of lane 4
-    for (int q = 1; q <= PARTIAL_ROUNDS; ++q) kq[q] = k_const[q - 1];
-    kq[PARTIAL_ROUNDS + 1] = closing_first[4];
-    for (int q = 6; q <= PARTIAL_ROUNDS + 1; ++q) {
-        FrHost acc = kq[q];
-        for (int m = 1; m <= 4; ++m) acc = acc - T.arma_a[m - 1] * kq[q - m];
-        T.arma_kappa[q - 6] = acc;
-    }
     {  // exit matrices
         FrHost O[4][4], Oinv[4][4], A4Oinv[4][4], Toep[4][4], A4OinvT[4][4];
         for (int r = 0; r < 4; ++r)
@@ -266,99 +267,23 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
                 T.exit_gv[i][s2] = kb - A4OinvT[i][s2];
                 T.exit_gy[i][s2] = A4Oinv[i][s2];
             }
-        for (int i = 0; i < 4; ++i) {
-            FrHost acc = closing_first[i];
-            for (int r = 0; r < 4; ++r) acc = acc - T.exit_gy[i][r] * kq[58 + r];
-            T.exit_add[i] = acc;
-        }
-    }
-    // direct entry: row q-1 of mds_entry = (c^T A^(q-1)) * M[0..3][:]  (q = 1..4), row 4 = M[4][:]
-    for (int q = 1; q <= 4; ++q)
-        for (int j = 0; j < WIDTH; ++j) {
-            FrHost acc = FrHost::zero();
-            for (int i = 0; i < 4; ++i) {
-                FrHost pi = FrHost::zero();  // (c^T A^(q-1))[i]
-                for (int r = 0; r < 4; ++r) pi = pi + cvec[r] * powA[q - 1][r][i];
-                acc = acc + pi * M[i][j];
-            }
-            T.mds_entry[q - 1][j] = acc;
-        }
-    for (int j = 0; j < WIDTH; ++j) T.mds_entry[4][j] = M[4][j];
-    for (int q = 1; q <= 4; ++q) T.entry_add[q - 1] = kq[q + 1];
-    T.entry_add[4] = kq[1];
-    for (int n = 0; n < 4; ++n) T.entry_g[n] = g[n];
-
-    // ---- (4) state re-scaling (see HadesTables).  tests/pymodel.py::derive_scaled is the big-int twin. ----
-    const FrHost tau = FrHost::pow2(20).inv();
-    const FrHost tau_inv = FrHost::pow2(20);
-    T.lam = (tau * T.arma_beta[3].inv()).fourth_root();  // exists: checked in tests (and asserted below by use)
-    const FrHost lam = T.lam, lam_inv = lam.inv();
-    const FrHost lam4 = (lam * lam) * (lam * lam), lam5 = lam4 * lam;
-    FrHost L[WIDTH];
-    for (int i = 0; i < WIDTH; ++i) L[i] = FrHost::one();
-    for (int r = 0; r < RF - 1; ++r) {  // opening rounds 0..2: column 0 normalised
-        FrHost L5[WIDTH], Ln[WIDTH];
-        for (int j = 0; j < WIDTH; ++j) L5[j] = L[j].pow5();
-        for (int i = 0; i < WIDTH; ++i) Ln[i] = M[i][0] * L5[0] * tau_inv;
-        for (int i = 0; i < WIDTH; ++i) {
-            const FrHost li = Ln[i].inv();
-            for (int j = 0; j < WIDTH; ++j) T.sc_mats[r][i][j] = li * M[i][j] * L5[j];
-            T.sc_adds[r][i] = li * C[r + 1][i];
-        }
-        for (int i = 0; i < WIDTH; ++i) L[i] = Ln[i];
-    }
-    {  // round 3 = entry matrix, scaled by 1/lam (its outputs are the partial phase's scaled projections and u_1)
-        FrHost L5[WIDTH];
-        for (int j = 0; j < WIDTH; ++j) L5[j] = L[j].pow5();
-        for (int i = 0; i < WIDTH; ++i) {
-            for (int j = 0; j < WIDTH; ++j) T.sc_mats[RF - 1][i][j] = lam_inv * T.mds_entry[i][j] * L5[j];
-            T.sc_adds[RF - 1][i] = lam_inv * T.entry_add[i];
-        }
-    }
-    for (int n = 0; n < 4; ++n) T.entry_g[n] = g[n] * lam4;
-    for (int n = 0; n < 5; ++n) T.arma_beta[n] = T.arma_beta[n] * lam4;  // arma_beta[3] == tau now
-    for (int q = 0; q < PARTIAL_ROUNDS - 4; ++q) T.arma_kappa[q] = T.arma_kappa[q] * lam_inv;
-    FrHost Lc[WIDTH];  // scale of the state leaving the exit: rows 0..3 normalise the coefficient of v_60
-    for (int i = 0; i < 4; ++i) Lc[i] = T.exit_gv[i][3] * lam5 * tau_inv;
-    Lc[4] = lam;
-    for (int i = 0; i < 4; ++i) {
-        const FrHost li = Lc[i].inv();
-        for (int r = 0; r < 4; ++r) {
-            T.exit_gy[i][r] = li * T.exit_gy[i][r] * lam;
-            T.exit_gv[i][r] = li * T.exit_gv[i][r] * lam5;
-        }
-        T.exit_add[i] = li * T.exit_add[i];
-    }
-    for (int i = 0; i < WIDTH; ++i) L[i] = Lc[i];
-    for (int f = RF; f < FULL_ROUNDS; ++f) {  // closing rounds: 4,5,6 normalised, 7 outputs the true state
-        const bool last = f == FULL_ROUNDS - 1;
-        FrHost L5[WIDTH], Ln[WIDTH];
-        for (int j = 0; j < WIDTH; ++j) L5[j] = L[j].pow5();
-        for (int i = 0; i < WIDTH; ++i) Ln[i] = last ? FrHost::one() : M[i][0] * L5[0] * tau_inv;
-        for (int i = 0; i < WIDTH; ++i) {
-            const FrHost li = Ln[i].inv();
-            for (int j = 0; j < WIDTH; ++j) T.sc_mats[f][i][j] = li * M[i][j] * L5[j];
-            T.sc_adds[f][i] = last ? FrHost::zero() : li * C[f + PARTIAL_ROUNDS + 1][i];
-        }
-        for (int i = 0; i < WIDTH; ++i) L[i] = Ln[i];
     }
 
-    // ---- (5) integer-MDS schedule.  M = (R/L) N with N[i][j] = L/(i+j+5) a one-digit integer, so the linear
-    // layer costs 9 MACs per term; the field factor R/L lives in the scale s_k of the stored state
-    // (stored = s_k * true S-box input, the same s_k on all five lanes), which x -> x^5 turns into s_k^5:
+    // ================= (B) integer MDS, all rounds =================
+    //   stored Z = s_k * (true S-box input of round k), one scale for all five lanes
     //   full round     X_j = Z_j^5 / R'^4                                   scale e = s^5 / R'^4
     //   partial round  X_j = Z_j (j<4), X_4 = Z_4^5/R'^4 * G_k/R'           G_k = R'^5 / s^4  =>  e = s
     //   linear layer   Z'_i = (sum_j N_ij X_j + kappa_i) / 2^29             s' = e L / (R 2^29),
     //                                                                       kappa_i = 2^29 s' C_{k+1}[i]
     //   after round 67 out_i R = Z'_i F / R',  F = R R' / s_68.     tests/pymodel.py::derive_int is the twin.
+    const FrHost RP = FrHost::pow2(261), RM = FrHost::pow2(256), T29 = FrHost::pow2(29);
+    const FrHost RP4inv = ((RP * RP) * (RP * RP)).inv(), RP5 = (RP * RP) * (RP * RP) * RP;
+    const FrHost step = FrHost::from_u64((uint64_t)INT_L) * RM.inv() * T29.inv();
+    T.int_ok = true;
+    for (int i = 0; i < WIDTH; ++i)
+        for (int j = 0; j < WIDTH; ++j)  // a different mds.bin must not pass silently
+            if (!(M[i][j] * FrHost::from_u64((uint64_t)(i + j + 5)) == RM)) T.int_ok = false;
     {
-        T.int_ok = true;
-        for (int i = 0; i < WIDTH; ++i)
-            for (int j = 0; j < WIDTH; ++j)  // a different mds.bin must not pass silently
-                if (!(M[i][j] * FrHost::from_u64((uint64_t)(i + j + 5)) == FrHost::pow2(256))) T.int_ok = false;
-        const FrHost RP = FrHost::pow2(261), RM = FrHost::pow2(256), T29 = FrHost::pow2(29);
-        const FrHost RP4inv = ((RP * RP) * (RP * RP)).inv(), RP5 = (RP * RP) * (RP * RP) * RP;
-        const FrHost step = FrHost::from_u64((uint64_t)INT_L) * RM.inv() * T29.inv();
         FrHost s = RM;
         for (int k = 0; k < ROUNDS; ++k) {
             const bool full = k < RF || k >= RF + PARTIAL_ROUNDS;
@@ -374,19 +299,174 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
         }
         T.int_f = RM * RP * s.inv();
     }
+
+    // ================= (C) integer ARMA =================
+    // a_m = R^m a~_m and beta_n = R^(n+1) b~_n with A_m = a~_m D^m, B_n = b~_n D^n K one-digit integers.
+    // Stored U_q = sigma_q u_q with sigma_{q+1} = sigma_q mu, mu = D / (R 2^29); W_q = (sigma_q D / K) v_q =
+    // sbox(U_q) * G_q / R' with G_q = R'^5 D / (K sigma_q^4).  Then (hades29.hpp::ai_round)
+    //   U_{q+1} = ( sum_m A_m U_{q+1-m} 2^(29(5-m)) + sum_n B_n W_{q-n} 2^(29(4-n)) ) / 2^145 + K_{q+1},
+    //   K_{q+1} = sigma_{q+1} kappa_{q+1}.
+    // All additive constants come from the zero-input trajectory of the affine system (they are
+    // trajectory-independent).  Entry: (u_0, u_-1, u_-2, v_0) = H y_1 + h_0 (y_1 = state entering the first
+    // partial round) is the virtual history for which the recurrence already holds at q = 1..4 with
+    // kappa_2..5 = 0 and v_-1.. = 0.  tests/pymodel.py::derive_armaint is the twin.
+    {
+        const FrHost Df = FrHost::from_u64((uint64_t)INT_D), Kf = FrHost::from_u64((uint64_t)INT_K);
+        for (int m = 1; m <= 4; ++m)
+            if (!(T.arma_a[m - 1] * fr_pow_u(Df, m) == fr_pow_u(RM, m) * fr_from_i64(ARMA_A_INT[m - 1]))) T.int_ok = false;
+        for (int n = 0; n < 5; ++n)
+            if (!(T.arma_beta[n] * fr_pow_u(Df, n) * Kf == fr_pow_u(RM, n + 1) * fr_from_i64(ARMA_B_INT[n]))) T.int_ok = false;
+        const FrHost* a = T.arma_a;
+        const FrHost* beta = T.arma_beta;
+        // zero-input trajectory from the first partial-round state y1 (5 lanes): u[q], x[q] for q = 1..61
+        struct Traj {
+            FrHost x[PARTIAL_ROUNDS + 2][4], u[PARTIAL_ROUNDS + 2];
+        };
+        auto traj = [&](const FrHost y1[WIDTH], Traj& t) {
+            for (int i = 0; i < 4; ++i) t.x[1][i] = y1[i];
+            t.u[1] = y1[4];
+            for (int q = 1; q <= PARTIAL_ROUNDS; ++q) {
+                const int k = RF + q;  // constants added after partial round q
+                for (int i = 0; i < 4; ++i) {
+                    FrHost acc = C[k][i];
+                    for (int j = 0; j < 4; ++j) acc = acc + A[i][j] * t.x[q][j];
+                    t.x[q + 1][i] = acc;
+                }
+                FrHost acc = C[k][4];
+                for (int j = 0; j < 4; ++j) acc = acc + cvec[j] * t.x[q][j];
+                t.u[q + 1] = acc;
+            }
+        };
+        auto residuals = [&](const Traj& t, FrHost r[4]) {
+            for (int q = 1; q <= 4; ++q) {
+                FrHost acc = t.u[q + 1];
+                for (int m = 1; m <= 4; ++m)
+                    if (q + 1 - m >= 1) acc = acc - a[m - 1] * t.u[q + 1 - m];
+                r[q - 1] = acc;
+            }
+        };
+        const FrHost a4inv = a[3].inv(), b4inv = beta[4].inv();
+        auto solve = [&](const FrHost r[4], FrHost th[4]) {  // th = (u_0, u_-1, u_-2, v_0)
+            const FrHost v0 = r[3] * b4inv;
+            const FrHost um0 = (r[2] - beta[3] * v0) * a4inv;
+            const FrHost um1 = (r[1] - beta[2] * v0 - a[2] * um0) * a4inv;
+            const FrHost um2 = (r[0] - beta[1] * v0 - a[1] * um0 - a[2] * um1) * a4inv;
+            th[0] = um0, th[1] = um1, th[2] = um2, th[3] = v0;
+        };
+        std::vector<Traj> tr(2);
+        Traj &t0 = tr[0], &tj = tr[1];
+        FrHost zero5[WIDTH];
+        for (int i = 0; i < WIDTH; ++i) zero5[i] = FrHost::zero();
+        traj(zero5, t0);
+        FrHost kappa[PARTIAL_ROUNDS + 2];  // kappa[q+1], q = 1..60
+        for (int q = 1; q <= PARTIAL_ROUNDS; ++q) {
+            if (q <= 4) {
+                kappa[q + 1] = FrHost::zero();
+                continue;
+            }
+            FrHost acc = t0.u[q + 1];
+            for (int m = 1; m <= 4; ++m) acc = acc - a[m - 1] * t0.u[q + 1 - m];
+            kappa[q + 1] = acc;
+        }
+        FrHost exit_add[4];
+        for (int i = 0; i < 4; ++i) {
+            FrHost acc = t0.x[PARTIAL_ROUNDS + 1][i];
+            for (int r = 0; r < 4; ++r) acc = acc - T.exit_gy[i][r] * t0.u[58 + r];
+            exit_add[i] = acc;
+        }
+        FrHost r0[4], th0[4], H[4][WIDTH];
+        residuals(t0, r0);
+        solve(r0, th0);
+        for (int j = 0; j < WIDTH; ++j) {
+            FrHost e[WIDTH];
+            for (int i = 0; i < WIDTH; ++i) e[i] = (i == j) ? FrHost::one() : FrHost::zero();
+            traj(e, tj);
+            FrHost rj[4], col[4];
+            residuals(tj, rj);
+            for (int i = 0; i < 4; ++i) rj[i] = rj[i] - r0[i];
+            solve(rj, col);
+            for (int i = 0; i < 4; ++i) H[i][j] = col[i];
+        }
+        // ---- scales ----
+        const FrHost mu = Df * RM.inv() * T29.inv();
+        const FrHost mu_inv = mu.inv();
+        FrHost s = RM, sigma1 = FrHost::one(), e3 = FrHost::one();
+        for (int k = 0; k < RF; ++k) {
+            const FrHost e = s.pow5() * RP4inv;
+            const FrHost sn = e * step;
+            for (int i = 0; i < WIDTH; ++i) T.ai_kappa[k][i] = (k < RF - 1 || i == 4) ? T29 * sn * C[k + 1][i] : FrHost::zero();
+            if (k == RF - 1) sigma1 = sn, e3 = e;
+            s = sn;
+        }
+        FrHost sig[PARTIAL_ROUNDS + 5];  // sig[q + 2] = sigma_q for q = -2..61
+        sig[3] = sigma1;
+        for (int q = 2; q <= PARTIAL_ROUNDS + 1; ++q) sig[q + 2] = sig[q + 1] * mu;
+        for (int q = 0; q >= -2; --q) sig[q + 2] = sig[q + 3] * mu_inv;
+        const FrHost DK = Df * Kf.inv();
+        {  // entry rows: theta_i = sum_j (H M)_ij v_j + (H C_4 + h0)_i,  v_j = X_j / e3
+            const FrHost tscale[4] = {sig[0 + 2], sig[-1 + 2], sig[-2 + 2], sig[0 + 2] * DK};
+            const FrHost e3inv = e3.inv();
+            for (int i = 0; i < 4; ++i) {
+                FrHost hc = th0[i];
+                for (int t = 0; t < WIDTH; ++t) hc = hc + H[i][t] * C[RF][t];
+                T.ai_ent_add[i] = tscale[i] * hc;
+                for (int j = 0; j < WIDTH; ++j) {
+                    FrHost hm = FrHost::zero();
+                    for (int t = 0; t < WIDTH; ++t) hm = hm + H[i][t] * M[t][j];
+                    T.ai_ent_mul[i][j] = tscale[i] * hm * e3inv * RP;
+                }
+            }
+        }
+        for (int q = 1; q <= PARTIAL_ROUNDS; ++q) {
+            const FrHost s2 = sig[q + 2] * sig[q + 2];
+            T.ai_g[q - 1] = RP5 * DK * (s2 * s2).inv();
+            T.ai_k[q - 1] = sig[q + 1 + 2] * kappa[q + 1];
+        }
+        s = sig[PARTIAL_ROUNDS + 1 + 2];
+        for (int i = 0; i < 4; ++i) {
+            for (int r = 0; r < 4; ++r) {
+                T.ai_ex_gy[i][r] = s * T.exit_gy[i][r] * sig[58 + r + 2].inv() * RP;
+                T.ai_ex_gv[i][r] = s * T.exit_gv[i][r] * (sig[57 + r + 2] * DK).inv() * RP;
+            }
+            T.ai_ex_add[i] = s * exit_add[i];
+        }
+        for (int k = RF + PARTIAL_ROUNDS; k < ROUNDS; ++k) {
+            s = s.pow5() * RP4inv * step;
+            for (int i = 0; i < WIDTH; ++i)
+                T.ai_kappa[k - PARTIAL_ROUNDS][i] = k + 1 < ROUNDS ? T29 * s * C[k + 1][i] : FrHost::zero();
+        }
+        T.ai_f = RM * RP * s.inv();
+    }
 }
 
 // =============================================================================================
 // Device encoding for the 29-bit-limb kernels (fr29.hpp)
 // =============================================================================================
 // Flat int32 table, 9 digits per constant, balanced digits in [-2^28, 2^28] of the CENTRED integer
-// representative (|n| <= p/2):
+// representative (|n| <= p/2).  Schedule (A): field values in one of three forms
 //   additive constants ("A"):  n = a * 2^256            (same form as the state)
 //   multipliers of plain state lanes ("MP"): n = c * 2^261          (redc divides by 2^261)
 //   multipliers of S-box outputs ("MS"):     n = c * 2^261 * 2^20   (S-box output carries 2^-20)
+// Schedules (B), (C): the residues of HadesTables as they are ("raw"), plus plain one-digit integers.
 struct Tab29Layout {
-    static constexpr int C_FIRST = 0;                                   // [5][9]   A
-    static constexpr int FULL_ADD = C_FIRST + WIDTH * NL;               // [8][5][9] A
+    static constexpr int C_FIRST = 0;                                   // [5][9]   A     (all schedules)
+    // ---- (C) integer ARMA: what the kernels read ----
+    static constexpr int INT_N = C_FIRST + WIDTH * NL;                  // [9] ints: N[i][j] = h[i+j], h[d] = L/(d+5)
+    static constexpr int AI_AB = INT_N + NL;                            // [9] ints: A_1..A_4, B_0..B_4
+    static constexpr int AI_KAPPA = AI_AB + NL;                         // [8][5][9] raw
+    static constexpr int AI_ENT_MUL = AI_KAPPA + FULL_ROUNDS * WIDTH * NL;  // [4][5][9] raw
+    static constexpr int AI_ENT_ADD = AI_ENT_MUL + 4 * WIDTH * NL;      // [4][9] raw
+    static constexpr int AI_KG = AI_ENT_ADD + 4 * NL;                   // [60][2][9] raw: K_{q+1}, G_q per round (contiguous)
+    static constexpr int AI_EX_GY = AI_KG + PARTIAL_ROUNDS * 2 * NL;    // [4][4][9] raw
+    static constexpr int AI_EX_GV = AI_EX_GY + 16 * NL;                 // [4][4][9] raw
+    static constexpr int AI_EX_ADD = AI_EX_GV + 16 * NL;                // [4][9] raw
+    static constexpr int AI_F = AI_EX_ADD + 4 * NL;                     // [9] raw
+    // ---- (B) integer MDS in all rounds (host cross-check) ----
+    static constexpr int INT_KAPPA = AI_F + NL;                         // [68][5][9] raw
+    static constexpr int INT_G = INT_KAPPA + ROUNDS * WIDTH * NL;       // [60][9] raw
+    static constexpr int INT_F = INT_G + PARTIAL_ROUNDS * NL;           // [9] raw
+    // ---- (A) sparse (host cross-check) ----
+    static constexpr int FULL_ADD = INT_F + NL;                         // [8][5][9] A
     static constexpr int MDS = FULL_ADD + FULL_ROUNDS * WIDTH * NL;     // [5][5][9] MS
     static constexpr int MDS_PRE = MDS + WIDTH * WIDTH * NL;            // [5][5][9] MS
     static constexpr int SPARSE = MDS_PRE + WIDTH * WIDTH * NL;         // [60][SPARSE_STRIDE]
@@ -394,21 +474,7 @@ struct Tab29Layout {
     static constexpr int SP_W = 0, SP_D = 4 * NL, SP_B = 5 * NL, SP_ADD4 = 9 * NL;
     static constexpr int SPARSE_STRIDE = 10 * NL;
     static constexpr int LAST_ADD = SPARSE + PARTIAL_ROUNDS * SPARSE_STRIDE;  // [4][9] A
-    static constexpr int ARMA_A = LAST_ADD + 4 * NL;                          // [4][9] MP  (a_1..a_4)
-    static constexpr int ARMA_BETA = ARMA_A + 4 * NL;                         // [5][9] MS  (beta_0..beta_4)
-    static constexpr int ARMA_KAPPA = ARMA_BETA + 5 * NL;                     // [56][9] A  (kappa_6..kappa_61)
-    static constexpr int EXIT_GY = ARMA_KAPPA + (PARTIAL_ROUNDS - 4) * NL;    // [4][4][9] MP
-    static constexpr int EXIT_GV = EXIT_GY + 16 * NL;                         // [4][4][9] MS
-    static constexpr int EXIT_ADD = EXIT_GV + 16 * NL;                        // [4][9] A
-    static constexpr int SC_MATS = EXIT_ADD + 4 * NL;                         // [8][5][5][9] MS  per-round matrices
-    static constexpr int SC_ADDS = SC_MATS + FULL_ROUNDS * WIDTH * WIDTH * NL;  // [8][5][9] A
-    static constexpr int ENTRY_G = SC_ADDS + FULL_ROUNDS * WIDTH * NL;        // [4][9] MS  (g_0..g_3, scaled)
-    // integer-MDS schedule: raw residues (digits encode the value itself)
-    static constexpr int INT_N = ENTRY_G + 4 * NL;                            // [9] one int each: N[i][j] = h[i+j], h[d] = L/(d+5)
-    static constexpr int INT_KAPPA = INT_N + NL;                              // [68][5][9]
-    static constexpr int INT_G = INT_KAPPA + ROUNDS * WIDTH * NL;             // [60][9]
-    static constexpr int INT_F = INT_G + PARTIAL_ROUNDS * NL;                 // [9]
-    static constexpr int TOTAL = INT_F + NL;
+    static constexpr int TOTAL = LAST_ADD + 4 * NL;
 };
 
 inline void encode_balanced29(const FrHost& field_value, int32_t out[NL]) {
@@ -451,8 +517,35 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
     const FrHost fA = FrHost::pow2(256);
     const FrHost fMP = FrHost::pow2(261);
     const FrHost fMS = FrHost::pow2(261 + 20);
+    const FrHost one = FrHost::one();
     auto put = [&](int off, const FrHost& v, const FrHost& scale) { encode_balanced29(v * scale, &tab[off]); };
     for (int i = 0; i < WIDTH; ++i) put(Lay::C_FIRST + i * NL, T.c_first[i], fA);
+    // (C)
+    for (int d = 0; d < 2 * WIDTH - 1; ++d) tab[Lay::INT_N + d] = INT_L / (d + 5);
+    for (int m = 0; m < 4; ++m) tab[Lay::AI_AB + m] = ARMA_A_INT[m];
+    for (int n = 0; n < 5; ++n) tab[Lay::AI_AB + 4 + n] = ARMA_B_INT[n];
+    for (int f = 0; f < FULL_ROUNDS; ++f)
+        for (int i = 0; i < WIDTH; ++i) put(Lay::AI_KAPPA + (f * WIDTH + i) * NL, T.ai_kappa[f][i], one);
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < WIDTH; ++j) put(Lay::AI_ENT_MUL + (i * WIDTH + j) * NL, T.ai_ent_mul[i][j], one);
+        put(Lay::AI_ENT_ADD + i * NL, T.ai_ent_add[i], one);
+        for (int r = 0; r < 4; ++r) {
+            put(Lay::AI_EX_GY + (i * 4 + r) * NL, T.ai_ex_gy[i][r], one);
+            put(Lay::AI_EX_GV + (i * 4 + r) * NL, T.ai_ex_gv[i][r], one);
+        }
+        put(Lay::AI_EX_ADD + i * NL, T.ai_ex_add[i], one);
+    }
+    for (int q = 0; q < PARTIAL_ROUNDS; ++q) {
+        put(Lay::AI_KG + (q * 2 + 0) * NL, T.ai_k[q], one);
+        put(Lay::AI_KG + (q * 2 + 1) * NL, T.ai_g[q], one);
+    }
+    put(Lay::AI_F, T.ai_f, one);
+    // (B)
+    for (int k = 0; k < ROUNDS; ++k)
+        for (int i = 0; i < WIDTH; ++i) put(Lay::INT_KAPPA + (k * WIDTH + i) * NL, T.int_kappa[k][i], one);
+    for (int q = 0; q < PARTIAL_ROUNDS; ++q) put(Lay::INT_G + q * NL, T.int_g[q], one);
+    put(Lay::INT_F, T.int_f, one);
+    // (A)
     for (int f = 0; f < FULL_ROUNDS; ++f)
         for (int i = 0; i < WIDTH; ++i) put(Lay::FULL_ADD + (f * WIDTH + i) * NL, T.full_add[f][i], fA);
     for (int i = 0; i < WIDTH; ++i)
@@ -468,54 +561,31 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
         put(base + Lay::SP_ADD4, T.sparse[q].add4, fA);
     }
     for (int i = 0; i < 4; ++i) put(Lay::LAST_ADD + i * NL, T.last_add[i], fA);
-    for (int m = 0; m < 4; ++m) put(Lay::ARMA_A + m * NL, T.arma_a[m], fMP);
-    for (int n = 0; n < 5; ++n) put(Lay::ARMA_BETA + n * NL, T.arma_beta[n], fMS);
-    for (int q = 0; q < PARTIAL_ROUNDS - 4; ++q) put(Lay::ARMA_KAPPA + q * NL, T.arma_kappa[q], fA);
-    for (int i = 0; i < 4; ++i)
-        for (int r = 0; r < 4; ++r) {
-            put(Lay::EXIT_GY + (i * 4 + r) * NL, T.exit_gy[i][r], fMP);
-            put(Lay::EXIT_GV + (i * 4 + r) * NL, T.exit_gv[i][r], fMS);
-        }
-    for (int i = 0; i < 4; ++i) put(Lay::EXIT_ADD + i * NL, T.exit_add[i], fA);
-    for (int f = 0; f < FULL_ROUNDS; ++f)
-        for (int i = 0; i < WIDTH; ++i) {
-            for (int j = 0; j < WIDTH; ++j) put(Lay::SC_MATS + ((f * WIDTH + i) * WIDTH + j) * NL, T.sc_mats[f][i][j], fMS);
-            put(Lay::SC_ADDS + (f * WIDTH + i) * NL, T.sc_adds[f][i], fA);
-        }
-    for (int n = 0; n < 4; ++n) put(Lay::ENTRY_G + n * NL, T.entry_g[n], fMS);
-    const FrHost one = FrHost::one();
-    for (int d = 0; d < 2 * WIDTH - 1; ++d) tab[Lay::INT_N + d] = INT_L / (d + 5);
-    for (int k = 0; k < ROUNDS; ++k)
-        for (int i = 0; i < WIDTH; ++i) put(Lay::INT_KAPPA + (k * WIDTH + i) * NL, T.int_kappa[k][i], one);
-    for (int q = 0; q < PARTIAL_ROUNDS; ++q) put(Lay::INT_G + q * NL, T.int_g[q], one);
-    put(Lay::INT_F, T.int_f, one);
     return tab;
 }
 
-// Worst-case |column| (as a double) over every lazy accumulation the schedules perform, for the
-// ACTUAL constants in `tab`: state digits are bounded by 2^29 (top digit by 2^25: |V| < 4p), the
-// high-column initialisation by 2^30, and the reduction adds at most 2^29 * sum(p digits) + carries.
-// The kernels are correct iff this stays below 2^63.
+// Worst-case |column| (as a double) over every lazy accumulation the three schedules perform, for the
+// ACTUAL constants in `tab`: state digits are bounded by 2^29 (un-carried lanes of schedule (B) by 2^30.1,
+// top digits by 2^25: |V| < 4p), the high-column initialisation by 2^30, and a full reduction adds at most
+// 2^29 * sum(p digits) + carries.  The kernels are correct iff this stays below 2^63.
 inline double max_column_bound29(const int32_t* tab) {
     typedef Tab29Layout Lay;
-    const double DIG = 536870912.0 /* 2^29 */, TOP = 33554432.0 /* 2^25 */;
+    const double DIG = 536870912.0 /* 2^29 */, TOP = 33554432.0 /* 2^25 */, LAZY = 1151000000.0 /* 2^30.1 */;
     const double P_SUM = (double)P252_P29_1 + P252_P29_2 + P252_P29_3 + P252_P29_4 + P252_P29_5 + P252_P29_6 +
                          P252_P29_7 + P252_P29_8;
     const double REDC = DIG * P_SUM + 68719476736.0 /* carries < 2^36 */ + 1073741824.0 /* hi init 2^30 */;
     double worst = 0;
-    auto group = [&](std::initializer_list<int> offsets) {
+    auto absd = [](int32_t v) { return v < 0 ? -(double)v : (double)v; };
+    auto group = [&](std::initializer_list<int> offsets) {  // sum of 9-digit x 9-digit products into 18 columns
         double col[2 * NL] = {0};
         for (int off : offsets)
-            for (int j = 0; j < NL; ++j) {
-                const double cj = tab[off + j] < 0 ? -(double)tab[off + j] : (double)tab[off + j];
-                for (int i = 0; i < NL; ++i) col[i + j] += (i == NL - 1 ? TOP : DIG) * cj;
-            }
+            for (int j = 0; j < NL; ++j)
+                for (int i = 0; i < NL; ++i) col[i + j] += (i == NL - 1 ? TOP : DIG) * absd(tab[off + j]);
         for (int k = 0; k < 2 * NL; ++k)
             if (col[k] + REDC > worst) worst = col[k] + REDC;
     };
-    group({Lay::ENTRY_G, Lay::ENTRY_G + NL, Lay::ENTRY_G + 2 * NL, Lay::ENTRY_G + 3 * NL});
-    for (int base : {Lay::MDS, Lay::MDS_PRE, Lay::SC_MATS, Lay::SC_MATS + 225 * 1, Lay::SC_MATS + 225 * 2, Lay::SC_MATS + 225 * 3,
-                     Lay::SC_MATS + 225 * 4, Lay::SC_MATS + 225 * 5, Lay::SC_MATS + 225 * 6, Lay::SC_MATS + 225 * 7})
+    // (A)
+    for (int base : {Lay::MDS, Lay::MDS_PRE})
         for (int k = 0; k < WIDTH; ++k)
             group({base + (k * 5 + 0) * NL, base + (k * 5 + 1) * NL, base + (k * 5 + 2) * NL, base + (k * 5 + 3) * NL,
                    base + (k * 5 + 4) * NL});
@@ -524,18 +594,30 @@ inline double max_column_bound29(const int32_t* tab) {
         group({b + Lay::SP_W, b + Lay::SP_W + NL, b + Lay::SP_W + 2 * NL, b + Lay::SP_W + 3 * NL, b + Lay::SP_D});
         for (int i = 0; i < 4; ++i) group({b + Lay::SP_B + i * NL});
     }
-    group({Lay::ARMA_A, Lay::ARMA_A + NL, Lay::ARMA_A + 2 * NL, Lay::ARMA_A + 3 * NL, Lay::ARMA_BETA,
-           Lay::ARMA_BETA + NL, Lay::ARMA_BETA + 2 * NL, Lay::ARMA_BETA + 3 * NL, Lay::ARMA_BETA + 4 * NL});
-    for (int i = 0; i < 4; ++i)
-        group({Lay::EXIT_GY + (i * 4 + 0) * NL, Lay::EXIT_GY + (i * 4 + 1) * NL, Lay::EXIT_GY + (i * 4 + 2) * NL,
-               Lay::EXIT_GY + (i * 4 + 3) * NL, Lay::EXIT_GV + (i * 4 + 0) * NL, Lay::EXIT_GV + (i * 4 + 1) * NL,
-               Lay::EXIT_GV + (i * 4 + 2) * NL, Lay::EXIT_GV + (i * 4 + 3) * NL});
-    for (int q = 0; q < PARTIAL_ROUNDS; ++q) group({Lay::INT_G + q * NL});
+    // (B), (C): generic products
+    for (int q = 0; q < PARTIAL_ROUNDS; ++q) {
+        group({Lay::INT_G + q * NL});
+        group({Lay::AI_KG + (q * 2 + 1) * NL});
+    }
     group({Lay::INT_F});
-    {  // integer rows: nine columns, five one-digit terms + kappa, then one digit step
+    group({Lay::AI_F});
+    for (int i = 0; i < 4; ++i) {
+        group({Lay::AI_ENT_MUL + (i * 5 + 0) * NL, Lay::AI_ENT_MUL + (i * 5 + 1) * NL, Lay::AI_ENT_MUL + (i * 5 + 2) * NL,
+               Lay::AI_ENT_MUL + (i * 5 + 3) * NL, Lay::AI_ENT_MUL + (i * 5 + 4) * NL});
+        group({Lay::AI_EX_GY + (i * 4 + 0) * NL, Lay::AI_EX_GY + (i * 4 + 1) * NL, Lay::AI_EX_GY + (i * 4 + 2) * NL,
+               Lay::AI_EX_GY + (i * 4 + 3) * NL, Lay::AI_EX_GV + (i * 4 + 0) * NL, Lay::AI_EX_GV + (i * 4 + 1) * NL,
+               Lay::AI_EX_GV + (i * 4 + 2) * NL, Lay::AI_EX_GV + (i * 4 + 3) * NL});
+    }
+    {  // integer rows: five one-digit terms (row 0 has the largest sum) of possibly un-carried lanes + kappa + one digit step
         double nsum = 0;
-        for (int j = 0; j < WIDTH; ++j) nsum += (double)tab[Lay::INT_N + j];  // row 0 is the largest
-        const double row = DIG * nsum + 268435456.0 /* kappa digit */ + DIG * (double)P252_P29_1 + 68719476736.0;
+        for (int j = 0; j < WIDTH; ++j) nsum += absd(tab[Lay::INT_N + j]);
+        const double row = LAZY * nsum + 268435456.0 + DIG * (double)P252_P29_1 + 68719476736.0;
+        if (row > worst) worst = row;
+    }
+    {  // integer ARMA row: a column collects at most one digit of each of the nine terms, then five digit steps
+        double asum = 0;
+        for (int t = 0; t < NL; ++t) asum += absd(tab[Lay::AI_AB + t]);
+        const double row = DIG * asum + 5.0 * DIG * (double)P252_P29_1 + 268435456.0 + 68719476736.0;
         if (row > worst) worst = row;
     }
     // S-box: element x element (9 products of 2^29 x 2^29) and squarings (<= 4.5 * 2^59)

@@ -485,3 +485,168 @@ def perm_int(x_mont, C=None, M=None, T=None):
             X = Z[:4] + [mm(sbox(Z[4]), T["G"][k])]
         Z = [(sum(N_INT[i][j] * X[j] for j in range(5)) + T["kappa"][k][i]) * i29 % P for i in range(5)]
     return [mm(z, T["F"]) for z in Z]
+
+
+# ------------------------------------------------------------------------------------------------
+# Schedule 5 — integer MDS in the full rounds + integer ARMA recurrence in the partial rounds
+#
+# The 60 partial rounds are the 4th-order linear system of derive_arma (u = S-box input, v = u^5):
+#     u_{q+1} = sum_m a_m u_{q+1-m} + sum_n beta_n v_{q-n} + kappa_{q+1}
+# With M = R * Cauchy the coefficients are a_m = R^m a~_m, beta_n = R^(n+1) b~_n with RATIONAL a~, b~ whose
+# scaled forms A_m = a~_m D^m (D = 27720) and B_n = b~_n D^n K (K = 12870) are ONE-DIGIT INTEGERS (< 2^25).
+# Stored values carry geometric scales  U_q = sigma_q u_q, sigma_{q+1} = sigma_q D / (R 2^29), and
+# W_q = (sigma_q D / K) v_q  (= sbox(U_q) times one generic constant G_q, the only generic product of a round),
+# so that a term of age j sits j digits lower in the accumulator:
+#     U_{q+1} = ( sum_m A_m U_{q+1-m} 2^(29(5-m)) + sum_n B_n W_{q-n} 2^(29(4-n)) ) / 2^(29*5) + K_{q+1}
+# = 81 one-digit MACs + 5 Montgomery digit steps, instead of five 5-term rows.
+# Entry: the linear layer of full round 3 produces U_1 (lane 4, integer row) and a VIRTUAL history
+# (U_0, U_-1, U_-2, W_0; older v's are zero) — four generic rows — chosen so that the recurrence already holds for
+# q = 1..4.  Exit: lanes 0..3 of the state are recovered from (U_58..U_61, W_57..W_60) by four generic rows.
+# All additive constants are obtained from the zero-input trajectory of the affine system (they do not depend
+# on the trajectory), so no closed form for pushed constants is needed.
+# ------------------------------------------------------------------------------------------------
+D_INT, K_INT = 27720, 12870
+
+
+def _rational_arma():
+    from fractions import Fraction as Fr
+    C5 = [[Fr(1, i + j + 5) for j in range(5)] for i in range(5)]
+    A = [r[:4] for r in C5[:4]]
+    b = [C5[i][4] for i in range(4)]
+    c = C5[4][:4]
+    d = C5[4][4]
+    mm = lambda X, Y: [[sum(X[i][k] * Y[k][j] for k in range(len(Y))) for j in range(len(Y[0]))] for i in range(len(X))]
+    I4 = [[Fr(int(i == j)) for j in range(4)] for i in range(4)]
+    Mk, ck, cs = [[Fr(0)] * 4 for _ in range(4)], Fr(1), []
+    for k in range(1, 5):  # Faddeev-LeVerrier
+        AMk = mm(A, Mk) if k > 1 else [[Fr(0)] * 4 for _ in range(4)]
+        Mk = [[AMk[i][j] + ck * I4[i][j] for j in range(4)] for i in range(4)]
+        AM = mm(A, Mk)
+        ck = -sum(AM[i][i] for i in range(4)) / k
+        cs.append(ck)
+    a = [-x for x in cs]
+    h, row = [d], c[:]
+    for _ in range(4):
+        h.append(sum(row[i] * b[i] for i in range(4)))
+        row = [sum(row[i] * A[i][j] for i in range(4)) for j in range(4)]
+    beta = [h[n] - sum(a[m - 1] * h[n - m] for m in range(1, n + 1)) for n in range(5)]
+    Aint = [a[m - 1] * D_INT ** m for m in range(1, 5)]
+    Bint = [beta[n] * D_INT ** n * K_INT for n in range(5)]
+    assert all(x.denominator == 1 for x in Aint + Bint)
+    return [int(x) for x in Aint], [int(x) for x in Bint]
+
+
+A_INT, B_INT = _rational_arma()   # [15104, -4729406, 18244864, -419265], [990, -1555121, 23296324, -2924911, 1694]
+
+
+def derive_armaint(C, M):
+    inv = lambda v: pow(v, -1, P)
+    Rf = FULL // 2
+    AR = derive_arma(C, M)
+    a, beta, Gy, Gv = AR["a"], AR["beta"], AR["Gy"], AR["Gv"]
+    assert all(a[m - 1] == pow(RM, m, P) * A_INT[m - 1] % P * inv(pow(D_INT, m, P)) % P for m in range(1, 5))
+    assert all(beta[n] == pow(RM, n + 1, P) * B_INT[n] % P * inv(pow(D_INT, n, P) * K_INT) % P for n in range(5))
+    A4 = [row[:4] for row in M[:4]]
+    cvec = M[4][:4]
+    # ---- zero-input trajectory of the affine system (v = 0 everywhere), from an arbitrary first state y1 ----
+    def traj(y1):
+        x, u = {1: list(y1[:4])}, {1: y1[4]}
+        for q in range(1, PARTIAL + 1):
+            k = Rf + q  # constants added after partial round q are C[k] (k <= 64)
+            x[q + 1] = [(sum(A4[i][j] * x[q][j] for j in range(4)) + C[k][i]) % P for i in range(4)]
+            u[q + 1] = (sum(cvec[j] * x[q][j] for j in range(4)) + C[k][4]) % P
+        return x, u
+    x0, u0 = traj([0] * 5)
+    kappa = {q + 1: (u0[q + 1] - sum(a[m - 1] * u0[q + 1 - m] for m in range(1, 5))) % P for q in range(5, PARTIAL + 1)}
+    for q in range(1, 5):
+        kappa[q + 1] = 0
+    exit_add = [(x0[61][i] - sum(Gy[i][r] * u0[58 + r] for r in range(4))) % P for i in range(4)]
+    # ---- virtual history theta = (u_0, u_-1, u_-2, v_0) = H y1 + h0 from the residuals r_q (q = 1..4) ----
+    def residuals(y1):
+        _, u = traj(y1)
+        return [(u[q + 1] - sum(a[m - 1] * u[q + 1 - m] for m in range(1, 5) if q + 1 - m >= 1)) % P for q in range(1, 5)]
+    def solve(r):
+        v0 = r[3] * inv(beta[4]) % P
+        um0 = (r[2] - beta[3] * v0) * inv(a[3]) % P
+        um1 = (r[1] - beta[2] * v0 - a[2] * um0) * inv(a[3]) % P
+        um2 = (r[0] - beta[1] * v0 - a[1] * um0 - a[2] * um1) * inv(a[3]) % P
+        return [um0, um1, um2, v0]
+    th0 = solve(residuals([0] * 5))
+    H = [[0] * 5 for _ in range(4)]
+    for j in range(5):
+        e = [0] * 5
+        e[j] = 1
+        r0, rj = residuals([0] * 5), residuals(e)
+        col = solve([(rj[i] - r0[i]) % P for i in range(4)])  # linear part: offsets cancel (solve is linear)
+        for i in range(4):
+            H[i][j] = col[i]
+    # ---- scales ----
+    out = dict(c_first=[c * RM % P for c in C[0]], fr_kappa={}, ent_mul=None, ent_add=None, K={}, G={}, ex_gy=None, ex_gv=None,
+               ex_add=None)
+    i29 = inv(pow(2, 29, P))
+    step = L_INT * inv(RM) % P * i29 % P
+    s = RM
+    for k in range(Rf):  # opening full rounds; the layer of round 3 is the entry
+        e = pow(s, 5, P) * inv(pow(RP, 4, P)) % P
+        s_next = e * step % P
+        if k < Rf - 1:
+            out["fr_kappa"][k] = [pow(2, 29, P) * s_next % P * C[k + 1][i] % P for i in range(5)]
+        else:
+            sigma1 = s_next
+            mu = D_INT * inv(RM) % P * i29 % P
+            sig = lambda q: sigma1 * pow(mu, q - 1, P) % P          # also for q <= 0
+            omg = lambda q: sig(q) * D_INT % P * inv(K_INT) % P
+            # theta_i = sum_j (H M)_ij v_j + (H C_4 + h0)_i with v_j = X_j / e
+            HM = [[sum(H[i][t] * M[t][j] for t in range(5)) % P for j in range(5)] for i in range(4)]
+            hc = [(sum(H[i][t] * C[Rf][t] for t in range(5)) + th0[i]) % P for i in range(4)]
+            tscale = [sig(0), sig(-1), sig(-2), omg(0)]
+            out["ent_mul"] = [[tscale[i] * HM[i][j] % P * inv(e) % P * RP % P for j in range(5)] for i in range(4)]   # "MP": coefficient * R'
+            out["ent_add"] = [tscale[i] * hc[i] % P for i in range(4)]
+            out["fr_kappa"][k] = [0, 0, 0, 0, pow(2, 29, P) * s_next % P * C[Rf][4] % P]
+        s = s_next
+    for q in range(1, PARTIAL + 1):
+        out["G"][q] = pow(RP, 5, P) * D_INT % P * inv(K_INT) % P * inv(pow(sig(q), 4, P)) % P
+        out["K"][q + 1] = sig(q + 1) * kappa[q + 1] % P
+    s = sig(61)
+    out["ex_gy"] = [[s * Gy[i][r] % P * inv(sig(58 + r)) % P * RP % P for r in range(4)] for i in range(4)]
+    out["ex_gv"] = [[s * Gv[i][t] % P * inv(omg(57 + t)) % P * RP % P for t in range(4)] for i in range(4)]
+    out["ex_add"] = [s * exit_add[i] % P for i in range(4)]
+    for k in range(Rf + PARTIAL, ROUNDS):
+        e = pow(s, 5, P) * inv(pow(RP, 4, P)) % P
+        s = e * step % P
+        out["fr_kappa"][k] = [pow(2, 29, P) * s % P * C[k + 1][i] % P for i in range(5)] if k + 1 < ROUNDS else [0] * 5
+    out["F"] = RM * RP % P * inv(s) % P
+    return out
+
+
+def perm_armaint(x_mont, C=None, M=None, T=None):
+    if C is None:
+        C, M = load_constants()
+    if T is None:
+        T = derive_armaint(C, M)
+    inv = lambda v: pow(v, -1, P)
+    iRP, i29 = inv(RP), inv(pow(2, 29, P))
+    mm = lambda a, b: a * b % P * iRP % P
+    sbox = lambda z: mm(mm(mm(z, z), mm(z, z)), z)
+    irow = lambda X, i, kap: (sum(N_INT[i][j] * X[j] for j in range(5)) + kap) * i29 % P
+    grow = lambda terms, add: (sum(x * n for x, n in terms) % P * iRP + add) % P   # generic row: redc(sum x*n) + add
+    Rf = FULL // 2
+    Z = [(x_mont[i] + T["c_first"][i]) % P for i in range(5)]
+    for k in range(Rf - 1):
+        X = [sbox(z) for z in Z]
+        Z = [irow(X, i, T["fr_kappa"][k][i]) for i in range(5)]
+    X = [sbox(z) for z in Z]
+    th = [grow([(X[j], T["ent_mul"][i][j]) for j in range(5)], T["ent_add"][i]) for i in range(4)]
+    U = {1: irow(X, 4, T["fr_kappa"][Rf - 1][4]), 0: th[0], -1: th[1], -2: th[2]}
+    W = {0: th[3], -1: 0, -2: 0, -3: 0}
+    i145 = pow(i29, 5, P)
+    for q in range(1, PARTIAL + 1):
+        W[q] = mm(sbox(U[q]), T["G"][q])
+        acc = sum(A_INT[m - 1] * U[q + 1 - m] << (29 * (5 - m)) for m in range(1, 5)) + sum(B_INT[n] * W[q - n] << (29 * (4 - n)) for n in range(5))
+        U[q + 1] = (acc * i145 + T["K"][q + 1]) % P
+    Z = [grow([(U[58 + r], T["ex_gy"][i][r]) for r in range(4)] + [(W[57 + t], T["ex_gv"][i][t]) for t in range(4)], T["ex_add"][i])
+         for i in range(4)] + [U[61]]
+    for k in range(Rf + PARTIAL, ROUNDS):
+        X = [sbox(z) for z in Z]
+        Z = [irow(X, i, T["fr_kappa"][k][i]) for i in range(5)]
+    return [mm(z, T["F"]) for z in Z]

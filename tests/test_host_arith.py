@@ -96,11 +96,11 @@ def test_table_digit_bounds(hosttest_lib):
     assert all(abs(v) <= P // 2 + 1 for v in vals)
 
 
-def test_both_schedules_match_oracle(oracle_mod, hosttest_lib):
-    """sparse-only and ARMA schedules are two independent derivations; both must equal the oracle"""
+def test_all_schedules_match_oracle(oracle_mod, hosttest_lib):
+    """integer-ARMA (kernels), sparse and integer-MDS schedules are three independent derivations; all must equal the oracle"""
     st = oracle_mod.fill_random(21, 5 * 600).reshape(600, 5, 4)
     exp = oracle_mod.permute_batch(st)
-    for sched in (0, 1):
+    for sched in (0, 1, 2):
         out = np.empty_like(st)
         hosttest_lib.ht_permute29_sched(p(st), p(out), st.shape[0], sched)
         assert np.array_equal(out, exp), "schedule %d" % sched
@@ -116,37 +116,61 @@ def test_arma_bigint_model_equals_reference():
 
 
 def test_static_column_bound(hosttest_lib):
-    """worst-case |column| of every lazy accumulation (9-term ARMA dot included), for the actual
-    constants, stays below 2^63: int64 columns cannot overflow for ANY input"""
+    """worst-case |column| of every lazy accumulation of the three schedules, for the actual constants,
+    stays below 2^63: int64 columns cannot overflow for ANY input"""
     import math
     hosttest_lib.ht_max_column_bound29.restype = ctypes.c_double
     b = hosttest_lib.ht_max_column_bound29()
     assert 60 < math.log2(b) < 62.9, math.log2(b)
 
 
-def test_scaled_tables_match_bigint_derivation(oracle_mod, hosttest_lib):
-    """csrc/tables.hpp step (4) (state re-scaling: one free coefficient per row) vs tests/pymodel.py::derive_scaled,
-    using the library's choice among the four 4th roots"""
-    n = 1 + 200 + 40 + 4 + 4 + 5 + 56 + 16 + 16 + 4
-    raw = np.empty((n, 4), dtype=np.uint64)
-    hosttest_lib.ht_tables_scaled_raw.restype = ctypes.c_size_t
-    assert hosttest_lib.ht_tables_scaled_raw(p(raw)) == n
-    got = [oracle_mod.int_from_mont(v) for v in raw]
+def _canon(raw):
+    return [sum(int(v[i]) << (64 * i) for i in range(4)) for v in raw]
+
+
+def test_integer_mds_tables_match_bigint_derivation(hosttest_lib):
+    """csrc/tables.hpp (B) vs tests/pymodel.py::derive_int, and the big-int model of that schedule vs the reference"""
     C, M = pymodel.load_constants()
-    lam = got[0]
-    S = pymodel.derive_scaled(C, M, lam=lam)
-    exp = [lam] + [S["mats"][f][i][j] for f in range(8) for i in range(5) for j in range(5)]
-    exp += [S["adds"][f][i] for f in range(8) for i in range(5)]
-    exp += list(S["entry_g"]) + list(S["arma_a"]) + list(S["arma_beta"]) + [S["arma_kappa"][q] for q in range(6, 62)]
-    exp += [S["exit_gy"][i][r] for i in range(4) for r in range(4)] + [S["exit_gv"][i][r] for i in range(4) for r in range(4)]
-    exp += list(S["exit_add"])
-    assert got == exp
-    # the normalised coefficients are exactly tau = 2^-20 (device encoding 2^261 -> a plain addition)
-    assert S["arma_beta"][3] == pymodel.TAU and all(S["exit_gv"][i][3] == pymodel.TAU for i in range(4))
-    assert all(S["mats"][f][i][0] == pymodel.TAU for f in (0, 1, 2, 4, 5, 6) for i in range(5))
-    rng = random.Random(12)
+    T = pymodel.derive_int(C, M)
+    n = 340 + 60 + 1
+    raw = np.empty((n, 4), dtype=np.uint64)
+    hosttest_lib.ht_tables_int_raw.restype = ctypes.c_size_t
+    assert hosttest_lib.ht_tables_int_raw(p(raw)) == n
+    exp = [T["kappa"][k][i] for k in range(68) for i in range(5)] + [T["G"][k] for k in range(4, 64)] + [T["F"]]
+    assert _canon(raw) == exp
+    rng = random.Random(5)
     x = [rng.randrange(P) for _ in range(5)]
-    assert pymodel.perm_scaled(x, C, M, S) == pymodel.perm_reference(x, C, M)
+    assert pymodel.perm_int([v * pymodel.RM % P for v in x], C, M, T) == [v * pymodel.RM % P for v in pymodel.perm_reference(x, C, M)]
+
+
+def test_integer_arma_tables_match_bigint_derivation(hosttest_lib):
+    """csrc/tables.hpp (C) — what the kernels run — vs tests/pymodel.py::derive_armaint (independent derivation:
+    exact fractions for the integer coefficients, big ints for the residues), and the big-int model vs the reference"""
+    C, M = pymodel.load_constants()
+    T = pymodel.derive_armaint(C, M)
+    n = 40 + 20 + 4 + 120 + 16 + 16 + 4 + 1
+    raw = np.empty((n, 4), dtype=np.uint64)
+    hosttest_lib.ht_tables_armaint_raw.restype = ctypes.c_size_t
+    assert hosttest_lib.ht_tables_armaint_raw(p(raw)) == n
+    fr = dict(T["fr_kappa"])
+    exp = [fr[k][i] for k in (0, 1, 2, 3, 64, 65, 66, 67) for i in range(5)]
+    exp += [T["ent_mul"][i][j] for i in range(4) for j in range(5)] + list(T["ent_add"])
+    for q in range(1, 61):
+        exp += [T["K"][q + 1], T["G"][q]]
+    exp += [T["ex_gy"][i][r] for i in range(4) for r in range(4)] + [T["ex_gv"][i][r] for i in range(4) for r in range(4)]
+    exp += list(T["ex_add"]) + [T["F"]]
+    assert _canon(raw) == exp
+    # the integer coefficients the device table carries are the ones exact rational arithmetic gives
+    hosttest_lib.ht_tables29_total.restype = ctypes.c_int
+    tab = np.empty(hosttest_lib.ht_tables29_total(), dtype=np.int32)
+    hosttest_lib.ht_tables29(tab.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    assert list(tab[45:54]) == [pymodel.L_INT // (d + 5) for d in range(9)]
+    assert list(tab[54:63]) == pymodel.A_INT + pymodel.B_INT
+    assert max(abs(v) for v in pymodel.A_INT + pymodel.B_INT) < 1 << 25
+    rng = random.Random(6)
+    for _ in range(2):
+        x = [rng.randrange(P) for _ in range(5)]
+        assert pymodel.perm_armaint([v * pymodel.RM % P for v in x], C, M, T) == [v * pymodel.RM % P for v in pymodel.perm_reference(x, C, M)]
 
 
 def test_adversarial_noncanonical_limbs(oracle_mod, hosttest_lib):
@@ -161,7 +185,7 @@ def test_adversarial_noncanonical_limbs(oracle_mod, hosttest_lib):
     states = [[rng.choice(pats) for _ in range(5)] for _ in range(40)] + [[pats[0]] * 5, [pats[8]] * 5]
     st = np.array([[oracle_mod.int_to_limbs(v) for v in s] for s in states], dtype=np.uint64)
     out = np.empty_like(st)
-    for sched in (0, 1):
+    for sched in (0, 1, 2):
         hosttest_lib.ht_permute29_sched(p(st), p(out), st.shape[0], sched)
         for s, o in zip(states, out):
             exp = pymodel.perm_reference([v * Rinv % P for v in s], C, M)
