@@ -11,21 +11,10 @@
 #include "hades29.hpp"
 #include "kernels.h"
 
-// ARMA rounds per loop iteration, per kernel.  Measured on MI355X with the re-scaled schedule (42->5 sponge,
-// 2^20 messages): unroll 1 / 2 / 4 = 2.80e8 / 2.92e8 / 2.41e8 perm/s (beyond 2 the code size and SGPR spills
-// win); the digest kernel k_merkle4 is flat from 4 to 8 (2.98e8) and keeps the header default of 4.
-// developer switch for occupancy experiments: -DP252_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
+// developer switches for A/B experiments (bench_tools/ab_variants.sh): -DP252_ARMA_UNROLL=n (hades29.hpp: ARMA rounds
+// per loop iteration) and -DP252_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' (occupancy of k_merkle4)
 #ifndef P252_WAVES_ATTR
 #define P252_WAVES_ATTR
-#endif
-#ifndef P252_UNROLL_PERMUTE
-#define P252_UNROLL_PERMUTE 2
-#endif
-#ifndef P252_UNROLL_SPONGE
-#define P252_UNROLL_SPONGE 2
-#endif
-#ifndef P252_UNROLL_PATH
-#define P252_UNROLL_PATH 2
 #endif
 
 namespace p252 {

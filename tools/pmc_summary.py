@@ -11,11 +11,14 @@ import sys
 def main():
     kern, units = sys.argv[1], float(sys.argv[2])
     agg = collections.defaultdict(list)
+    rows = []
     for d in sys.argv[3:]:
-        for r in csv.DictReader(open(os.path.join(d, "pmc_counter_collection.csv"))):
-            if kern in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                meta = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
+        rows += [r for r in csv.DictReader(open(os.path.join(d, "pmc_counter_collection.csv"))) if kern in r["Kernel_Name"]]
+    full = max(int(r["Grid_Size"]) for r in rows)  # the timed launches; smaller self-check launches of the same kernel are left out
+    for r in rows:
+        if int(r["Grid_Size"]) == full:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
     avg = {k: sum(v) / len(v) for k, v in agg.items()}
     print("# rocprofv3 --pmc summary for kernel *%s* (avg per dispatch over %d dispatches, separate passes per counter group)" % (kern, len(next(iter(agg.values())))))
     print("# grid=%s wg=%s vgpr=%s sgpr=%s scratch=%s lds=%s ; units (permutations) per launch = %d" % (meta + (units,)))

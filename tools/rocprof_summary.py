@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 results.db (rocpd sqlite) into the text table kept under profiles/.
-usage: rocprof_summary.py <results.db> [title]"""
+usage: rocprof_summary.py <results.db> [title] [warmup_launches=10]"""
 import sqlite3
 import sys
 
 
-def main(path, title=""):
+def main(path, title="", warm=10):
     db = sqlite3.connect(path)
     cur = db.cursor()
     print("# rocprofv3 --kernel-trace --stats summary%s" % ((": " + title) if title else ""))
@@ -17,6 +17,17 @@ def main(path, title=""):
     for name, calls, total, avg, mn, mx in rows:
         short = name.split("(")[0][-58:]
         print("%-60s %8d %14.1f %12.1f %12.1f %12.1f %6.2f%%" % (short, calls, total / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * total / tot))
+    print()
+    print("# timed launches only: grid == the kernel's largest grid (self-check launches of other sizes left out) and the")
+    print("# first %d such launches skipped (bench.py's warm-up: the clocks ramp from idle over ~10 launches)" % warm)
+    print("%-60s %8s %12s %12s %12s %14s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "warmup_avg_us"))
+    for (name,) in list(cur.execute("select distinct name from kernels")):
+        gmax = cur.execute("select max(grid_x) from kernels where name = ?", (name,)).fetchone()[0]
+        durs = [r[0] for r in cur.execute("select duration from kernels where name = ? and grid_x = ? order by start", (name, gmax))]
+        if len(durs) > warm + 1:
+            rest, head = durs[warm:], durs[:warm]
+            print("%-60s %8d %12.1f %12.1f %12.1f %14.1f" % (name.split("(")[0][-58:], len(rest), sum(rest) / len(rest) / 1e3, min(rest) / 1e3,
+                                                             max(rest) / 1e3, sum(head) / len(head) / 1e3))
     print()
     print("# per-kernel launch geometry / registers (first dispatch)")
     for r in cur.execute("select name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size from kernels group by name"):
@@ -33,4 +44,4 @@ def main(path, title=""):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", int(sys.argv[3]) if len(sys.argv) > 3 else 10)

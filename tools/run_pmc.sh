@@ -26,7 +26,7 @@ for p in $PASSES; do
     if [ "$p" = ktrace ]; then
         rm -rf "$OUT/ktrace"
         timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o kt -- \
-            python "$ROOT/bench.py" --workload "$WL" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/ktrace.log" 2>&1
+            python "$ROOT/bench.py" --workload "$WL" --no-cpu-baseline > "$OUT/ktrace.log" 2>&1
     else
         rm -rf "$OUT/pmc_$p"
         timeout 300 rocprofv3 --pmc $(counters $p) --kernel-trace --output-format csv -d "$OUT/pmc_$p" -o pmc -- \
