@@ -67,7 +67,8 @@ static const std::vector<int32_t>& host_tables() {
     static const std::vector<int32_t> tab = [] {
         HadesTables T;
         derive_tables(ARC_BIN, MDS_BIN, T);
-        return encode_tables29(T);
+        // the kernels' schedule rests on mds.bin being R/(i+j+5) (tables.hpp): never run it on anything else
+        return T.int_ok ? encode_tables29(T) : std::vector<int32_t>();
     }();
     return tab;
 }
@@ -80,7 +81,7 @@ static TagArg tag_arg(const uint64_t tag[4]) {
 
 extern "C" {
 
-const char* p252_version(void) { return "poseidon252_hip 0.1 (gfx950; 9x29-bit limbs; re-scaled ARMA partial rounds)"; }
+const char* p252_version(void) { return "poseidon252_hip 0.2 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence)"; }
 
 int p252_device_count(void) {
     int n = 0;
@@ -101,6 +102,10 @@ int p252_create(int device_id, p252_ctx** out) {
     p252_ctx* ctx = new p252_ctx();
     ctx->device = device_id;
     ctx->h_tab = host_tables();
+    if (ctx->h_tab.empty()) {
+        delete ctx;
+        return fail(nullptr, P252_ERR_INVALID_ARGUMENT, "p252_create: the built-in mds.bin is not the Cauchy matrix R/(i+j+5) the kernels' schedule requires");
+    }
     hipError_t e2 = hipSetDevice(device_id);
     if (e2 == hipSuccess) e2 = hipMalloc((void**)&ctx->d_tab, ctx->h_tab.size() * sizeof(int32_t));
     if (e2 == hipSuccess)

@@ -16,10 +16,6 @@
 #include "fr29.hpp"
 #include "tables.hpp"
 
-#ifndef P252_ARMA_UNROLL
-#define P252_ARMA_UNROLL 4
-#endif
-
 namespace p252 {
 
 // One full round of the sparse schedule: state <- Mat * sbox(state) + add   (ARC of this round was folded
@@ -143,21 +139,18 @@ P252_HD void hades_permute_int(E29 s[WIDTH], TP tab) {
 }
 
 // ---- schedule 3: integer MDS in the full rounds + integer ARMA recurrence in the partial rounds (tables.hpp (C)) ----
-// History while in the partial phase (q = index of the partial round about to run, 1..60):
-//   U[0..3] = U_q, U_{q-1}, U_{q-2}, U_{q-3}          (scaled S-box inputs)
-//   W[0..4] = W_{q-1} .. W_{q-5}                        -> after the S-box: W_q .. W_{q-4}
-// One step:  W_q = sbox(U_q) * G_q / R';
+// History of the partial phase: rings of HIST entries, U_q at Us[q mod HIST] and W_q at Ws[q mod HIST]; with
+// HIST rounds per loop iteration every ring position is a compile-time constant and nothing is ever moved.
+// One step (q = index of the partial round, 1..60):  W_q = sbox(U_q) * G_q / R';
 //   U_{q+1} = ( sum_m A_m U_{q+1-m} 2^(29(5-m)) + sum_n B_n W_{q-n} 2^(29(4-n)) ) / 2^145 + K_{q+1}
 // A term of age j sits j digits lower, so the nine one-digit products land in columns 0..12, five Montgomery
 // digit steps clear columns 0..4, and K (nine digits) is simply preloaded into columns 5..13.
-// ab = A_1..A_4, B_0..B_4 (ints); kg = K_{q+1}[9], G_q[9].
-template <class TP>
-P252_HD void ai_round(E29 U[4], E29 W[5], TP ab, TP kg) {
-    W[4] = W[3];
-    W[3] = W[2];
-    W[2] = W[1];
-    W[1] = W[0];
-    W[0] = mul_c(sbox(U[0]), kg + NL);
+// ab = A_1..A_4, B_0..B_4 (ints); kg = K_{q+1}[9], G_q[9].  U_{q+1} overwrites U_{q-4}, W_q overwrites W_{q-5}.
+constexpr int HIST = 5;
+template <int QM /* q mod HIST */, class TP>
+P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg) {
+    constexpr int Q = QM + HIST;  // keeps (Q - j) % HIST non-negative
+    Ws[Q % HIST] = mul_c(sbox(Us[Q % HIST]), kg + NL);
     int64_t c[NL + 5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) c[k] = 0;
@@ -167,12 +160,13 @@ P252_HD void ai_round(E29 U[4], E29 W[5], TP ab, TP kg) {
     for (int j = 0; j < 4; ++j) {  // base column 4 - j: A_{j+1} U_{q-j} and B_j W_{q-j}
         const int64_t aj = ab[j], bj = ab[4 + j];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) c[4 - j + k] += (int64_t)U[j].d[k] * aj + (int64_t)W[j].d[k] * bj;
+        for (int k = 0; k < NL; ++k)
+            c[4 - j + k] += (int64_t)Us[(Q - j) % HIST].d[k] * aj + (int64_t)Ws[(Q - j) % HIST].d[k] * bj;
     }
     {
         const int64_t b4 = ab[8];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) c[k] += (int64_t)W[4].d[k] * b4;
+        for (int k = 0; k < NL; ++k) c[k] += (int64_t)Ws[(Q - 4) % HIST].d[k] * b4;
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -195,10 +189,7 @@ P252_HD void ai_round(E29 U[4], E29 W[5], TP ab, TP kg) {
         carry = v >> WB;
     }
     r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 4] + carry));
-    U[3] = U[2];
-    U[2] = U[1];
-    U[1] = U[0];
-    U[0] = r;
+    Us[(Q + 1) % HIST] = r;
 }
 
 // sum_t x_t * mul_t / R' + add: a generic row (entry and exit of the partial phase)
@@ -211,29 +202,23 @@ P252_HD E29 gen_row(const E29* const x[TERMS], const TP mul[TERMS], TP add) {
     return redc(t);
 }
 
-// One loop with a wave-uniform phase switch, so each large unrolled body exists once in the instruction
-// stream.  Steps: 0-3 full (3 = entry: lanes 0..3 of its linear layer are the generic rows of the virtual history)
-// | 60/UNROLL ARMA steps | exit | 4 full.  OUT_ROWS: bit k set = lane k of the result is needed (a Merkle4
-// digest needs lane 1 only: the multiplication by F is done for that lane alone).
-template <unsigned OUT_ROWS = 0x1fu, int ARMA_UNROLL_T = P252_ARMA_UNROLL, class TP>
+// Loop nest: two halves, each = four full rounds (one copy of that body in the instruction stream), the first half
+// followed by the partial phase: 12 iterations of HIST = 5 ARMA rounds in a loop of their own (its loop-carried
+// values are exactly the two history rings), then the exit rows.  Full round 3 is the entry: lanes 0..3 of its linear
+// layer are the generic rows of the virtual history.  OUT_ROWS: bit k set = lane k of the result is needed (a
+// Merkle4 digest needs lane 1 only: the multiplication by F is done for that lane alone).
+template <unsigned OUT_ROWS = 0x1fu, class TP>
 P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
-    constexpr int UR = ARMA_UNROLL_T;  // ARMA rounds per loop step (history shifts become renames)
-    static_assert(PARTIAL_ROUNDS % UR == 0, "60 ARMA rounds must split evenly");
-    constexpr int STEP_EXIT = RF + PARTIAL_ROUNDS / UR;
-    constexpr int STEP_END = STEP_EXIT + 1 + RF;
+    static_assert(PARTIAL_ROUNDS % HIST == 0, "60 ARMA rounds must split evenly");
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
-    E29 U[4], W[5];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) U[i] = e29_zero();
-#pragma unroll
-    for (int i = 0; i < 5; ++i) W[i] = e29_zero();
 #pragma unroll 1
-    for (int step = 0; step < STEP_END; ++step) {
-        if (step < RF || step > STEP_EXIT) {
-            const int f = step < RF ? step : step - STEP_EXIT - 1 + RF;
+    for (int half = 0; half < 2; ++half) {
+        E29 Us[HIST], Ws[HIST];
+#pragma unroll 1
+        for (int f = half * RF; f < (half + 1) * RF; ++f) {
             const TP kap = tab + Lay::AI_KAPPA + f * WIDTH * NL;
             E29 x[WIDTH];
 #pragma unroll
@@ -248,22 +233,31 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
                                            tab + Lay::AI_ENT_MUL + (i * WIDTH + 4) * NL};
                     th[i] = gen_row<WIDTH>(xs, mul, tab + Lay::AI_ENT_ADD + i * NL);
                 }
-                U[0] = int_row(x, tab + Lay::INT_N + 4, kap + 4 * NL);  // U_1
-                U[1] = th[0];                                           // U_0, U_-1, U_-2: virtual
-                U[2] = th[1];
-                U[3] = th[2];
-                W[0] = th[3];                                           // W_0: virtual; W_-1.. = 0
+                Us[1] = int_row(x, tab + Lay::INT_N + 4, kap + 4 * NL);  // U_1
+                Us[0] = th[0];                                           // U_0, U_-1, U_-2: virtual
+                Us[HIST - 1] = th[1];
+                Us[HIST - 2] = th[2];
+                Us[2] = e29_zero();                                      // (free slot)
+                Ws[0] = th[3];                                           // W_0: virtual; W_-1, W_-2, W_-3 = 0
+#pragma unroll
+                for (int i = 1; i < HIST; ++i) Ws[i] = e29_zero();
             } else {
 #pragma unroll
                 for (int i = 0; i < WIDTH; ++i) s[i] = int_row(x, tab + Lay::INT_N + i, kap + i * NL);
             }
-        } else if (step < STEP_EXIT) {
-#pragma unroll
-            for (int r = 0; r < UR; ++r)
-                ai_round(U, W, tab + Lay::AI_AB, tab + Lay::AI_KG + ((step - RF) * UR + r) * 2 * NL);
-        } else {
-            // after round 60: U[0..3] = U_61..U_58, W[0..3] = W_60..W_57
-            const E29* const hs[8] = {&U[3], &U[2], &U[1], &U[0], &W[3], &W[2], &W[1], &W[0]};
+        }
+        if (half == 0) {
+#pragma unroll 1
+            for (int it = 0; it < PARTIAL_ROUNDS / HIST; ++it) {  // rounds q = 5 it + 1 .. 5 it + 5
+                const TP kg = tab + Lay::AI_KG + it * HIST * 2 * NL;
+                ai_round<1>(Us, Ws, tab + Lay::AI_AB, kg);
+                ai_round<2>(Us, Ws, tab + Lay::AI_AB, kg + 2 * NL);
+                ai_round<3>(Us, Ws, tab + Lay::AI_AB, kg + 4 * NL);
+                ai_round<4>(Us, Ws, tab + Lay::AI_AB, kg + 6 * NL);
+                ai_round<0>(Us, Ws, tab + Lay::AI_AB, kg + 8 * NL);
+            }
+            // after round 60 (60 mod 5 = 0): U_58..U_61 at Us[3], Us[4], Us[0], Us[1]; W_57..W_60 at Ws[2], Ws[3], Ws[4], Ws[0]
+            const E29* const hs[8] = {&Us[3], &Us[4], &Us[0], &Us[1], &Ws[2], &Ws[3], &Ws[4], &Ws[0]};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const TP mul[8] = {tab + Lay::AI_EX_GY + (i * 4 + 0) * NL, tab + Lay::AI_EX_GY + (i * 4 + 1) * NL,
@@ -272,7 +266,7 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
                                    tab + Lay::AI_EX_GV + (i * 4 + 2) * NL, tab + Lay::AI_EX_GV + (i * 4 + 3) * NL};
                 s[i] = gen_row<8>(hs, mul, tab + Lay::AI_EX_ADD + i * NL);
             }
-            s[4] = U[0];
+            s[4] = Us[1];
         }
     }
 #pragma unroll

@@ -11,8 +11,8 @@
 #include "hades29.hpp"
 #include "kernels.h"
 
-// developer switches for A/B experiments (bench_tools/ab_variants.sh): -DP252_ARMA_UNROLL=n (hades29.hpp: ARMA rounds
-// per loop iteration) and -DP252_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' (occupancy of k_merkle4)
+// developer switch for A/B experiments (bench_tools/ab_variants.sh):
+// -DP252_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' (occupancy of k_merkle4)
 #ifndef P252_WAVES_ATTR
 #define P252_WAVES_ATTR
 #endif
