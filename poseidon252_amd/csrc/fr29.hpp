@@ -11,13 +11,14 @@
 // instructions at all, and is Montgomery-reduced once.
 //
 // Representation ("E29"): value V = sum d[i] * 2^(29 i), d[0..7] in [0, 2^29), d[8] signed and small.
-// V is a LAZY residue: any integer congruent to x*R (R = 2^256, the reference's Montgomery radix)
-// with |V| < 4p.  Signs are tolerated everywhere (columns are signed 64-bit, multiplier constants
+// V is a LAZY residue with |V| < 4p: at the kernels' boundary any integer congruent to x*R (R = 2^256, the
+// reference's Montgomery radix); inside a permutation congruent to s*x for a known per-round scale s
+// (tables.hpp).  Signs are tolerated everywhere (columns are signed 64-bit, multiplier constants
 // are balanced digits in [-2^28, 2^28]); only to_mont4() canonicalises to [0, p).
 //
-// Montgomery reduction here divides by R' = 2^261 (9 digits), not by R.  The mismatch
-// rho = R/R' = 2^-5 is folded into the constant tables (tables.hpp), so it costs nothing at run
-// time: redc(V * n) with n = c*R' gives (c*x)*R for V = x*R.
+// Montgomery reduction here divides by R' = 2^261 (9 digits), not by R, and one-digit rows divide by
+// 2^29 per digit step.  Powers of two never cost anything: they are folded into the constant tables /
+// the scale of the stored values.
 //
 // All functions are __host__ __device__: the same code is unit-tested on the CPU against the
 // oracle (tests/test_host_arith.py) and runs in the kernels.
@@ -272,8 +273,9 @@ P252_HD E29 e29_zero() {
     return r;
 }
 
-// x^5 = (x^2)^2 * x  — scalar.rs:50-52.  With V = x*R the result is x^5 * R * rho^4 (rho = 2^-5);
-// the tables compensate (every constant that multiplies an S-box output carries 2^20).
+// x^5 = (x^2)^2 * x  — scalar.rs:50-52.  Three Montgomery products: the result is V^5 / R'^4; the tables
+// compensate (sparse schedule: every constant that multiplies an S-box output carries 2^20; integer schedules:
+// the factor rides in the scale of the stored state).
 P252_HD E29 sbox(const E29& x) {
     A29 t;
     acc_zero(t);

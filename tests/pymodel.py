@@ -1,5 +1,7 @@
-"""Pure-Python big-int model of the Hades permutation: reference schedule and the algebraically
-equivalent "sparse partial round" schedule the HIP kernels execute.  Test infrastructure.
+"""Pure-Python big-int models of the Hades permutation: the reference schedule and the algebraically
+equivalent schedules of poseidon252_amd/csrc/tables.hpp — sparse partial rounds, ARMA recurrence, integer MDS
+(schedule 4) and integer MDS + integer ARMA (schedule 5, what the HIP kernels execute) — each derived here
+independently of the C++.  Test infrastructure.
 
 Reference schedule: src/hades/permutation.rs:105-123 with scalar.rs:39-64
   round r:  x <- M * S_r(x + C_r)      (S on all 5 lanes in full rounds, on lane 4 in partial rounds)
@@ -276,150 +278,6 @@ def perm_arma(x, C=None, M=None, AR=None):
         if r < ROUNDS - 1:
             x = [(p + q) % P for p, q in zip(x, T["full_add"][r])]
     return x
-
-
-# ------------------------------------------------------------------------------------------------
-# Scaled schedule.  x^5 is homogeneous, so a diagonal scaling of the state commutes with an S-box
-# layer up to 5th powers:  with x = L (.) y,  M S(x) = M diag(L^5) S(y).  Re-scaling the state after
-# every linear layer lets ONE coefficient per output row be normalised to the constant tau whose
-# device encoding is exactly 2^261 — that product becomes a plain addition into the accumulator:
-#   * full rounds 0,1,2 and 64,65,66: column 0 of the round's matrix == tau      (5 products saved each)
-#   * ARMA rounds: a time-invariant scale lam with beta_3 * lam^4 == tau        (1 of 9 products saved)
-#   * exit: the coefficient of v_60 in each of the 4 rows == tau                  (4 products saved)
-# The last layer is not re-scaled, so the permutation's output is the true state.
-# ------------------------------------------------------------------------------------------------
-TAU = pow(2, -20, P)  # value c whose "MS" encoding c * 2^20 * 2^261 is 2^261: redc(v * 2^261) = v
-
-
-def sqrt_mod(a):
-    """Tonelli-Shanks (p - 1 = 2^32 * odd)"""
-    a %= P
-    if a == 0:
-        return 0
-    assert pow(a, (P - 1) // 2, P) == 1
-    q, s = P - 1, 0
-    while q % 2 == 0:
-        q //= 2
-        s += 1
-    z = 2
-    while pow(z, (P - 1) // 2, P) != P - 1:
-        z += 1
-    m, c, t, r = s, pow(z, q, P), pow(a, q, P), pow(a, (q + 1) // 2, P)
-    while t != 1:
-        i, t2 = 0, t
-        while t2 != 1:
-            t2 = t2 * t2 % P
-            i += 1
-        b = pow(c, 1 << (m - i - 1), P)
-        m, c, t, r = i, b * b % P, t * b * b % P, r * b % P
-    return r
-
-
-def fourth_root(a):
-    r = sqrt_mod(a)
-    if pow(r, (P - 1) // 2, P) != 1:
-        r = P - r
-    return sqrt_mod(r)
-
-
-def derive_scaled(C, M, lam=None):
-    """lam: optionally one particular 4th root (there are four; any is valid)"""
-    AR = derive_arma(C, M)
-    T = AR["T"]
-    Rf = FULL // 2
-    inv = lambda v: pow(v, -1, P)
-    A = [row[:4] for row in M[:4]]
-    b = [M[i][4] for i in range(4)]
-    c = M[4][:4]
-    d = M[4][4]
-    # Markov parameters and constants k_q as in derive_arma
-    g = [d]
-    vec = b[:]
-    for _ in range(4):
-        g.append(sum(c[i] * vec[i] for i in range(4)) % P)
-        vec = matvec(A, vec)
-    k = [None] * 62
-    delta = [0] * 5
-    for q in range(1, PARTIAL + 1):
-        aq = [(delta[i] + C[Rf + q - 1][i]) % P for i in range(5)]
-        k[q] = aq[4]
-        delta = matvec(M, aq[:4] + [0])
-    closing = [(C[Rf + PARTIAL][i] + delta[i]) % P for i in range(5)]
-    # entry matrix rows (true): pi_q = c^T A^(q-1) M_top, row 4 = M[4]
-    powA = [[[1 if i == j else 0 for j in range(4)] for i in range(4)]]
-    for _ in range(4):
-        powA.append(matmul(powA[-1], A))
-    E = []
-    for q in range(1, 5):
-        piv = [sum(c[r] * powA[q - 1][r][i] for r in range(4)) % P for i in range(4)]
-        E.append([sum(piv[i] * M[i][j] for i in range(4)) % P for j in range(5)])
-    E.append(M[4][:])
-    e_add = [k[2], k[3], k[4], k[5], k[1]]
-    if lam is None:
-        lam = fourth_root(TAU * inv(AR["beta"][3]) % P)
-    assert AR["beta"][3] * pow(lam, 4, P) % P == TAU
-    out = dict(c_first=C[0], lam=lam)
-    # opening full rounds 0..2 (scaled, column 0 normalised), round 3 = entry (scaled by 1/lam, no normalisation)
-    L = [1] * 5
-    mats, adds, unit = [], [], []
-    for r in range(3):
-        L5 = [pow(v, 5, P) for v in L]
-        Lnext = [M[i][0] * L5[0] % P * inv(TAU) % P for i in range(5)]
-        mats.append([[inv(Lnext[i]) * M[i][j] % P * L5[j] % P for j in range(5)] for i in range(5)])
-        adds.append([inv(Lnext[i]) * C[r + 1][i] % P for i in range(5)])
-        unit.append(True)
-        assert all(mats[-1][i][0] == TAU for i in range(5))
-        L = Lnext
-    L5 = [pow(v, 5, P) for v in L]
-    mats.append([[inv(lam) * E[i][j] % P * L5[j] % P for j in range(5)] for i in range(5)])
-    adds.append([inv(lam) * e_add[i] % P for i in range(5)])
-    unit.append(False)
-    lam4, lam5 = pow(lam, 4, P), pow(lam, 5, P)
-    out["entry_g"] = [g[n] * lam4 % P for n in range(4)]
-    out["arma_a"] = AR["a"]
-    out["arma_beta"] = [AR["beta"][n] * lam4 % P for n in range(5)]
-    out["arma_kappa"] = {q: AR["kappa"][q] * inv(lam) % P for q in AR["kappa"]}
-    # exit rows i<4: normalise the coefficient of v_60 (Gv[i][3]); lane 4 keeps y_61
-    Lc = [AR["Gv"][i][3] * lam5 % P * inv(TAU) % P for i in range(4)] + [lam]
-    out["exit_gy"] = [[inv(Lc[i]) * AR["Gy"][i][r] % P * lam % P for r in range(4)] for i in range(4)]
-    out["exit_gv"] = [[inv(Lc[i]) * AR["Gv"][i][s] % P * lam5 % P for s in range(4)] for i in range(4)]
-    out["exit_add"] = [inv(Lc[i]) * AR["exit_add"][i] % P for i in range(4)]
-    assert all(out["exit_gv"][i][3] == TAU for i in range(4))
-    # closing full rounds 64..66 normalised, 67 not (output must be the true state)
-    L = Lc
-    for r in range(Rf + PARTIAL, ROUNDS):
-        L5 = [pow(v, 5, P) for v in L]
-        last = r == ROUNDS - 1
-        Lnext = [1] * 5 if last else [M[i][0] * L5[0] % P * inv(TAU) % P for i in range(5)]
-        mats.append([[inv(Lnext[i]) * M[i][j] % P * L5[j] % P for j in range(5)] for i in range(5)])
-        adds.append([0] * 5 if last else [inv(Lnext[i]) * C[r + 1][i] % P for i in range(5)])
-        unit.append(not last)
-        L = Lnext
-    out["mats"], out["adds"], out["unit"] = mats, adds, unit
-    return out
-
-
-def perm_scaled(x, C=None, M=None, S=None):
-    if C is None:
-        C, M = load_constants()
-    if S is None:
-        S = derive_scaled(C, M)
-    y = [(x[i] + S["c_first"][i]) % P for i in range(5)]
-    for f in range(4):
-        y = [(a + b) % P for a, b in zip(matvec(S["mats"][f], [pow(v, 5, P) for v in y]), S["adds"][f])]
-    pi, u, v = y[:4], {1: y[4]}, {j: 0 for j in range(-3, 1)}
-    for q in range(1, 5):
-        v[q] = pow(u[q], 5, P)
-        u[q + 1] = (pi[q - 1] + sum(S["entry_g"][n] * v[q - n] for n in range(4))) % P
-    for q in range(5, PARTIAL + 1):
-        v[q] = pow(u[q], 5, P)
-        u[q + 1] = (sum(S["arma_a"][m - 1] * u[q + 1 - m] for m in range(1, 5))
-                    + sum(S["arma_beta"][n] * v[q - n] for n in range(5)) + S["arma_kappa"][q + 1]) % P
-    y = [(sum(S["exit_gy"][i][r] * u[58 + r] for r in range(4)) + sum(S["exit_gv"][i][s] * v[57 + s] for s in range(4))
-          + S["exit_add"][i]) % P for i in range(4)] + [u[61]]
-    for f in range(4, 8):
-        y = [(a + b) % P for a, b in zip(matvec(S["mats"][f], [pow(t, 5, P) for t in y]), S["adds"][f])]
-    return y
 
 
 # ------------------------------------------------------------------------------------------------
