@@ -192,6 +192,54 @@ P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg) {
     Us[(Q + 1) % HIST] = r;
 }
 
+// Exit row i: lanes 0..3 of the state after round 60 from (U_58..U_61, W_57..W_60).  The coefficients are rationals
+// with a common denominator per row: eight two-digit integer products (term r of the U's at base column r + 1,
+// term t of the W's at base column t: one digit lower per round of age, as in ai_round), six Montgomery digit steps,
+// then ONE generic product by fix_i = 2^58 R' / den_i; add_i rides in the high columns.
+// n = 8 x (lo, hi) digits: U_58..U_61 then W_57..W_60.
+template <class TP>
+P252_HD E29 exit_row(const E29* const u[4], const E29* const w[4], TP n, TP fix, TP add) {
+    int64_t c[NL + 6];
+#pragma unroll
+    for (int k = 0; k < NL + 6; ++k) c[k] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t ylo = n[2 * r], yhi = n[2 * r + 1], vlo = n[8 + 2 * r], vhi = n[8 + 2 * r + 1];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            c[r + 1 + k] += (int64_t)u[r]->d[k] * ylo;
+            c[r + 2 + k] += (int64_t)u[r]->d[k] * yhi;
+            c[r + k] += (int64_t)w[r]->d[k] * vlo;
+            c[r + 1 + k] += (int64_t)w[r]->d[k] * vhi;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int64_t lo = opaque_digit((int32_t)((uint32_t)c[i] & DMASK));
+        c[i + 1] += (c[i] >> WB) - lo * (int64_t)P252_P29_1;
+        c[i + 2] -= lo * (int64_t)P252_P29_2;
+        c[i + 3] -= lo * (int64_t)P252_P29_3;
+        c[i + 4] -= lo * (int64_t)P252_P29_4;
+        c[i + 5] -= lo * (int64_t)P252_P29_5;
+        c[i + 6] -= lo * (int64_t)P252_P29_6;
+        c[i + 7] -= lo * (int64_t)P252_P29_7;
+        c[i + 8] -= lo * (int64_t)P252_P29_8;
+    }
+    E29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = c[6 + k] + carry;
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
+        carry = v >> WB;
+    }
+    r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 5] + carry));
+    A29 t;
+    acc_set_hi_c(t, add);
+    acc_mul(t, r, fix);
+    return redc(t);
+}
+
 // sum_t x_t * mul_t / R' + add: a generic row (entry and exit of the partial phase)
 template <int TERMS, class TP>
 P252_HD E29 gen_row(const E29* const x[TERMS], const TP mul[TERMS], TP add) {
@@ -204,7 +252,7 @@ P252_HD E29 gen_row(const E29* const x[TERMS], const TP mul[TERMS], TP add) {
 
 // Loop nest: two halves, each = four full rounds (one copy of that body in the instruction stream), the first half
 // followed by the partial phase: 12 iterations of HIST = 5 ARMA rounds in a loop of their own (its loop-carried
-// values are exactly the two history rings), then the exit rows.  Full round 3 is the entry: lanes 0..3 of its linear
+// values are exactly the two history rings), then the exit rows (exit_row).  Full round 3 is the entry: lanes 0..3 of its linear
 // layer are the generic rows of the virtual history.  OUT_ROWS: bit k set = lane k of the result is needed (a
 // Merkle4 digest needs lane 1 only: the multiplication by F is done for that lane alone).
 template <unsigned OUT_ROWS = 0x1fu, class TP>
@@ -257,15 +305,11 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
                 ai_round<0>(Us, Ws, tab + Lay::AI_AB, kg + 8 * NL);
             }
             // after round 60 (60 mod 5 = 0): U_58..U_61 at Us[3], Us[4], Us[0], Us[1]; W_57..W_60 at Ws[2], Ws[3], Ws[4], Ws[0]
-            const E29* const hs[8] = {&Us[3], &Us[4], &Us[0], &Us[1], &Ws[2], &Ws[3], &Ws[4], &Ws[0]};
+            const E29* const us[4] = {&Us[3], &Us[4], &Us[0], &Us[1]};
+            const E29* const ws[4] = {&Ws[2], &Ws[3], &Ws[4], &Ws[0]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const TP mul[8] = {tab + Lay::AI_EX_GY + (i * 4 + 0) * NL, tab + Lay::AI_EX_GY + (i * 4 + 1) * NL,
-                                   tab + Lay::AI_EX_GY + (i * 4 + 2) * NL, tab + Lay::AI_EX_GY + (i * 4 + 3) * NL,
-                                   tab + Lay::AI_EX_GV + (i * 4 + 0) * NL, tab + Lay::AI_EX_GV + (i * 4 + 1) * NL,
-                                   tab + Lay::AI_EX_GV + (i * 4 + 2) * NL, tab + Lay::AI_EX_GV + (i * 4 + 3) * NL};
-                s[i] = gen_row<8>(hs, mul, tab + Lay::AI_EX_ADD + i * NL);
-            }
+            for (int i = 0; i < 4; ++i)
+                s[i] = exit_row(us, ws, tab + Lay::AI_EX_N + i * 2 * NL, tab + Lay::AI_EX_FIX + i * NL, tab + Lay::AI_EX_ADD + i * NL);
             s[4] = Us[1];
         }
     }

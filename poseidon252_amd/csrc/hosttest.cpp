@@ -46,7 +46,7 @@ size_t ht_tables_raw(uint64_t* out) {
 }
 
 // integer-ARMA constants (residues, canonical words): ai_kappa[8][5], ent_mul[4][5], ent_add[4], then per round
-// q = 1..60: K_{q+1}, G_q; ex_gy[16], ex_gv[16], ex_add[4], F.  Returns the count, or 0 when mds.bin lacks the structure.
+// q = 1..60: K_{q+1}, G_q; ex_fix[4], ex_add[4], F.  Returns the count, or 0 when mds.bin lacks the structure.
 size_t ht_tables_armaint_raw(uint64_t* out) {
     HadesTables T;
     derive_tables(ARC_BIN, MDS_BIN, T);
@@ -57,8 +57,7 @@ size_t ht_tables_armaint_raw(uint64_t* out) {
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) put(T.ai_ent_mul[i][j]);
     for (int i = 0; i < 4; ++i) put(T.ai_ent_add[i]);
     for (int q = 0; q < 60; ++q) { put(T.ai_k[q]); put(T.ai_g[q]); }
-    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.ai_ex_gy[i][r]);
-    for (int i = 0; i < 4; ++i) for (int r = 0; r < 4; ++r) put(T.ai_ex_gv[i][r]);
+    for (int i = 0; i < 4; ++i) put(T.ai_ex_fix[i]);
     for (int i = 0; i < 4; ++i) put(T.ai_ex_add[i]);
     put(T.ai_f);
     return k;

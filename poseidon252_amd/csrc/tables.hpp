@@ -37,6 +37,17 @@ constexpr int32_t INT_L = 360360;  // lcm(5..13): INT_L/(i+j+5) is an integer be
 constexpr int32_t INT_D = 27720, INT_K = 12870;
 constexpr int32_t ARMA_A_INT[4] = {15104, -4729406, 18244864, -419265};
 constexpr int32_t ARMA_B_INT[5] = {990, -1555121, 23296324, -2924911, 1694};
+// Exit rows (lanes 0..3 after round 60 from U_58..U_61, W_57..W_60): D^(3-r) Gy~[i][r] and D^(3-t) K Gv~[i][t] are
+// rationals; with the row-wise common denominator den_i they are integers below 2^47 (two digits).
+constexpr int64_t EXIT_DEN_INT[4] = {114095520LL, 3422865600LL, 51342984000LL, 13446972000LL};
+constexpr int64_t EXIT_NY_INT[4][4] = {{-8614218690LL, 374845978529LL, -96605623422LL, 196355311LL},
+                                       {-141506549415LL, 6157981489484LL, -1602233112249LL, 4987354612LL},
+                                       {-1079458116660LL, 46977158603111LL, -12312746836236LL, 64898311033LL},
+                                       {-111443571855LL, 4850104782358LL, -1278622187073LL, 15013381034LL}};
+constexpr int64_t EXIT_NV_INT[4][4] = {{34804924LL, -60095168892LL, 478555604051LL, -31235164290LL},
+                                       {571743634LL, -987190198929LL, 7863736475042LL, -532253038680LL},
+                                       {4361446936LL, -7530617199006LL, 60001569615953LL, -4178036642670LL},
+                                       {450277058LL, -777463806933LL, 6195760216744LL, -441369753660LL}};
 
 struct SparseRound {
     FrHost w[4];    // row 4 of M''_q, columns 0..3
@@ -69,8 +80,7 @@ struct HadesTables {
     FrHost ai_ent_add[4];
     FrHost ai_k[PARTIAL_ROUNDS];          // K_{q+1} at [q-1], q = 1..60
     FrHost ai_g[PARTIAL_ROUNDS];          // G_q at [q-1]
-    FrHost ai_ex_gy[4][4];                // exit rows: multipliers of U_58..U_61
-    FrHost ai_ex_gv[4][4];                //            multipliers of W_57..W_60
+    FrHost ai_ex_fix[4];                  // exit rows: 2^58 R' / den_i (the one generic product of an exit row)
     FrHost ai_ex_add[4];
     FrHost ai_f;
 };
@@ -422,12 +432,16 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
             T.ai_g[q - 1] = RP5 * DK * (s2 * s2).inv();
             T.ai_k[q - 1] = sig[q + 1 + 2] * kappa[q + 1];
         }
+        // exit rows in integer form (hades29.hpp::exit_row):
+        //   Z_i = ( sum_r ny_ir U_{58+r} 2^(29(r+1)) + sum_t nv_it W_{57+t} 2^(29 t) ) / 2^174 * fix_i / R' + add_i
         s = sig[PARTIAL_ROUNDS + 1 + 2];
         for (int i = 0; i < 4; ++i) {
+            const FrHost den = FrHost::from_u64((uint64_t)EXIT_DEN_INT[i]);
             for (int r = 0; r < 4; ++r) {
-                T.ai_ex_gy[i][r] = s * T.exit_gy[i][r] * sig[58 + r + 2].inv() * RP;
-                T.ai_ex_gv[i][r] = s * T.exit_gv[i][r] * (sig[57 + r + 2] * DK).inv() * RP;
+                if (!(T.exit_gy[i][r] * fr_pow_u(Df, 3 - r) * den == fr_pow_u(RM, 3 - r) * fr_from_i64(EXIT_NY_INT[i][r]))) T.int_ok = false;
+                if (!(T.exit_gv[i][r] * fr_pow_u(Df, 3 - r) * Kf * den == fr_pow_u(RM, 4 - r) * fr_from_i64(EXIT_NV_INT[i][r]))) T.int_ok = false;
             }
+            T.ai_ex_fix[i] = FrHost::pow2(58) * den.inv() * RP;
             T.ai_ex_add[i] = s * exit_add[i];
         }
         for (int k = RF + PARTIAL_ROUNDS; k < ROUNDS; ++k) {
@@ -457,9 +471,9 @@ struct Tab29Layout {
     static constexpr int AI_ENT_MUL = AI_KAPPA + FULL_ROUNDS * WIDTH * NL;  // [4][5][9] raw
     static constexpr int AI_ENT_ADD = AI_ENT_MUL + 4 * WIDTH * NL;      // [4][9] raw
     static constexpr int AI_KG = AI_ENT_ADD + 4 * NL;                   // [60][2][9] raw: K_{q+1}, G_q per round (contiguous)
-    static constexpr int AI_EX_GY = AI_KG + PARTIAL_ROUNDS * 2 * NL;    // [4][4][9] raw
-    static constexpr int AI_EX_GV = AI_EX_GY + 16 * NL;                 // [4][4][9] raw
-    static constexpr int AI_EX_ADD = AI_EX_GV + 16 * NL;                // [4][9] raw
+    static constexpr int AI_EX_N = AI_KG + PARTIAL_ROUNDS * 2 * NL;     // [4][18] ints: 8 two-digit coefficients (lo, hi) + 2 pad per row
+    static constexpr int AI_EX_FIX = AI_EX_N + 4 * 2 * NL;              // [4][9] raw
+    static constexpr int AI_EX_ADD = AI_EX_FIX + 4 * NL;                // [4][9] raw
     static constexpr int AI_F = AI_EX_ADD + 4 * NL;                     // [9] raw
     // ---- (B) integer MDS in all rounds (host cross-check) ----
     static constexpr int INT_KAPPA = AI_F + NL;                         // [68][5][9] raw
@@ -529,10 +543,14 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < WIDTH; ++j) put(Lay::AI_ENT_MUL + (i * WIDTH + j) * NL, T.ai_ent_mul[i][j], one);
         put(Lay::AI_ENT_ADD + i * NL, T.ai_ent_add[i], one);
-        for (int r = 0; r < 4; ++r) {
-            put(Lay::AI_EX_GY + (i * 4 + r) * NL, T.ai_ex_gy[i][r], one);
-            put(Lay::AI_EX_GV + (i * 4 + r) * NL, T.ai_ex_gv[i][r], one);
+        for (int t = 0; t < 8; ++t) {  // balanced two-digit split: n = lo + hi 2^29, |lo| <= 2^28
+            const int64_t n = t < 4 ? EXIT_NY_INT[i][t] : EXIT_NV_INT[i][t - 4];
+            int64_t lo = n & (int64_t)DMASK;
+            if (lo > ((int64_t)1 << (WB - 1))) lo -= (int64_t)1 << WB;
+            tab[Lay::AI_EX_N + i * 2 * NL + 2 * t] = (int32_t)lo;
+            tab[Lay::AI_EX_N + i * 2 * NL + 2 * t + 1] = (int32_t)((n - lo) >> WB);
         }
+        put(Lay::AI_EX_FIX + i * NL, T.ai_ex_fix[i], one);
         put(Lay::AI_EX_ADD + i * NL, T.ai_ex_add[i], one);
     }
     for (int q = 0; q < PARTIAL_ROUNDS; ++q) {
@@ -604,9 +622,12 @@ inline double max_column_bound29(const int32_t* tab) {
     for (int i = 0; i < 4; ++i) {
         group({Lay::AI_ENT_MUL + (i * 5 + 0) * NL, Lay::AI_ENT_MUL + (i * 5 + 1) * NL, Lay::AI_ENT_MUL + (i * 5 + 2) * NL,
                Lay::AI_ENT_MUL + (i * 5 + 3) * NL, Lay::AI_ENT_MUL + (i * 5 + 4) * NL});
-        group({Lay::AI_EX_GY + (i * 4 + 0) * NL, Lay::AI_EX_GY + (i * 4 + 1) * NL, Lay::AI_EX_GY + (i * 4 + 2) * NL,
-               Lay::AI_EX_GY + (i * 4 + 3) * NL, Lay::AI_EX_GV + (i * 4 + 0) * NL, Lay::AI_EX_GV + (i * 4 + 1) * NL,
-               Lay::AI_EX_GV + (i * 4 + 2) * NL, Lay::AI_EX_GV + (i * 4 + 3) * NL});
+        group({Lay::AI_EX_FIX + i * NL});
+        // integer exit row: a column collects at most one digit product per coefficient digit (16 of them), then six digit steps
+        double nsum = 0;
+        for (int t = 0; t < 16; ++t) nsum += absd(tab[Lay::AI_EX_N + i * 2 * NL + t]);
+        const double row = DIG * nsum + 6.0 * DIG * (double)P252_P29_1 + 68719476736.0;
+        if (row > worst) worst = row;
     }
     {  // integer rows: five one-digit terms (row 0 has the largest sum) of possibly un-carried lanes + kappa + one digit step
         double nsum = 0;

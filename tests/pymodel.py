@@ -391,10 +391,43 @@ def _rational_arma():
     Aint = [a[m - 1] * D_INT ** m for m in range(1, 5)]
     Bint = [beta[n] * D_INT ** n * K_INT for n in range(5)]
     assert all(x.denominator == 1 for x in Aint + Bint)
-    return [int(x) for x in Aint], [int(x) for x in Bint]
+    # exit rows (observability form, as derive_arma): lanes 0..3 after round 60 = Gy (u_58..u_61) + Gv (v_57..v_60) + const.
+    # In the scaled variables the coefficients are D^(3-r) Gy~[i][r] and D^(3-s) K Gv~[i][s] (times powers of 2^-29):
+    # rationals whose row-wise common denominator den_i leaves integers below 2^47.
+    def inv4(Mx):
+        n = 4
+        aug = [row[:] + [Fr(int(i == j)) for j in range(n)] for i, row in enumerate(Mx)]
+        for col in range(n):
+            piv = next(r for r in range(col, n) if aug[r][col] != 0)
+            aug[col], aug[piv] = aug[piv], aug[col]
+            f = aug[col][col]
+            aug[col] = [v / f for v in aug[col]]
+            for r in range(n):
+                if r != col and aug[r][col] != 0:
+                    f = aug[r][col]
+                    aug[r] = [v - f * w for v, w in zip(aug[r], aug[col])]
+        return [row[n:] for row in aug]
+    powA = [I4]
+    for _ in range(4):
+        powA.append(mm(powA[-1], A))
+    O = [[sum(c[i] * powA[r][i][j] for i in range(4)) for j in range(4)] for r in range(4)]
+    Gy = mm(powA[4], inv4(O))
+    Toep = [[(h[r - t] if t <= r else Fr(0)) for t in range(4)] for r in range(4)]
+    GyT = mm(Gy, Toep)
+    Gv = [[sum(powA[3 - t][i][j] * b[j] for j in range(4)) - GyT[i][t] for t in range(4)] for i in range(4)]
+    from math import lcm
+    ex = []
+    for i in range(4):
+        cy = [Gy[i][r] * D_INT ** (3 - r) for r in range(4)]
+        cv = [Gv[i][t] * D_INT ** (3 - t) * K_INT for t in range(4)]
+        den = 1
+        for x in cy + cv:
+            den = lcm(den, x.denominator)
+        ex.append((den, [int(x * den) for x in cy], [int(x * den) for x in cv]))
+    return [int(x) for x in Aint], [int(x) for x in Bint], ex
 
 
-A_INT, B_INT = _rational_arma()   # [15104, -4729406, 18244864, -419265], [990, -1555121, 23296324, -2924911, 1694]
+A_INT, B_INT, EXIT_INT = _rational_arma()   # [15104, -4729406, 18244864, -419265], [990, -1555121, 23296324, -2924911, 1694]
 
 
 def derive_armaint(C, M):
@@ -439,8 +472,7 @@ def derive_armaint(C, M):
         for i in range(4):
             H[i][j] = col[i]
     # ---- scales ----
-    out = dict(c_first=[c * RM % P for c in C[0]], fr_kappa={}, ent_mul=None, ent_add=None, K={}, G={}, ex_gy=None, ex_gv=None,
-               ex_add=None)
+    out = dict(c_first=[c * RM % P for c in C[0]], fr_kappa={}, ent_mul=None, ent_add=None, K={}, G={}, ex_fix=None, ex_add=None)
     i29 = inv(pow(2, 29, P))
     step = L_INT * inv(RM) % P * i29 % P
     s = RM
@@ -466,8 +498,12 @@ def derive_armaint(C, M):
         out["G"][q] = pow(RP, 5, P) * D_INT % P * inv(K_INT) % P * inv(pow(sig(q), 4, P)) % P
         out["K"][q + 1] = sig(q + 1) * kappa[q + 1] % P
     s = sig(61)
-    out["ex_gy"] = [[s * Gy[i][r] % P * inv(sig(58 + r)) % P * RP % P for r in range(4)] for i in range(4)]
-    out["ex_gv"] = [[s * Gv[i][t] % P * inv(omg(57 + t)) % P * RP % P for t in range(4)] for i in range(4)]
+    # exit rows in integer form: Z_i = ( sum_r ny U_{58+r} 2^(29(r+1)) + sum_t nv W_{57+t} 2^(29 t) ) / 2^174 * fix_i / R' + add_i
+    for i in range(4):
+        den, ny, nv = EXIT_INT[i]
+        assert all(s * Gy[i][r] % P * inv(sig(58 + r)) % P == ny[r] * inv(den) % P * pow(i29, 3 - r, P) % P for r in range(4))
+        assert all(s * Gv[i][t] % P * inv(omg(57 + t)) % P == nv[t] * inv(den) % P * pow(i29, 4 - t, P) % P for t in range(4))
+    out["ex_fix"] = [pow(2, 58, P) * inv(EXIT_INT[i][0]) % P * RP % P for i in range(4)]
     out["ex_add"] = [s * exit_add[i] % P for i in range(4)]
     for k in range(Rf + PARTIAL, ROUNDS):
         e = pow(s, 5, P) * inv(pow(RP, 4, P)) % P
@@ -502,8 +538,13 @@ def perm_armaint(x_mont, C=None, M=None, T=None):
         W[q] = mm(sbox(U[q]), T["G"][q])
         acc = sum(A_INT[m - 1] * U[q + 1 - m] << (29 * (5 - m)) for m in range(1, 5)) + sum(B_INT[n] * W[q - n] << (29 * (4 - n)) for n in range(5))
         U[q + 1] = (acc * i145 + T["K"][q + 1]) % P
-    Z = [grow([(U[58 + r], T["ex_gy"][i][r]) for r in range(4)] + [(W[57 + t], T["ex_gv"][i][t]) for t in range(4)], T["ex_add"][i])
-         for i in range(4)] + [U[61]]
+    i174 = pow(i29, 6, P)
+    Z = []
+    for i in range(4):
+        _, ny, nv = EXIT_INT[i]
+        acc = sum(ny[r] * U[58 + r] << (29 * (r + 1)) for r in range(4)) + sum(nv[t] * W[57 + t] << (29 * t) for t in range(4))
+        Z.append(grow([(acc * i174 % P, T["ex_fix"][i])], T["ex_add"][i]))
+    Z.append(U[61])
     for k in range(Rf + PARTIAL, ROUNDS):
         X = [sbox(z) for z in Z]
         Z = [irow(X, i, T["fr_kappa"][k][i]) for i in range(5)]
