@@ -240,20 +240,71 @@ P252_HD E29 exit_row(const E29* const u[4], const E29* const w[4], TP n, TP fix,
     return redc(t);
 }
 
-// sum_t x_t * mul_t / R' + add: a generic row (entry and exit of the partial phase)
-template <int TERMS, class TP>
-P252_HD E29 gen_row(const E29* const x[TERMS], const TP mul[TERMS], TP add) {
+// Entry row i (virtual history U_0, U_-1, U_-2): an integer combination of the S-box outputs 0..3 of full round 3
+// (NDIG-digit coefficients, NDIG Montgomery digit steps), then ONE generic product by fix_i; add_i rides in the
+// high columns.  n = 4 x (lo, hi) digits.
+template <int NDIG, class TP>
+P252_HD E29 entry_row(const E29 x[WIDTH], TP n, TP fix, TP add) {
+    int64_t c[NL + NDIG];
+#pragma unroll
+    for (int k = 0; k < NL + NDIG; ++k) c[k] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t lo = n[2 * j], hi = n[2 * j + 1];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            c[k] += (int64_t)x[j].d[k] * lo;
+            if (NDIG == 2) c[k + 1] += (int64_t)x[j].d[k] * hi;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NDIG; ++i) {
+        const int64_t lo = opaque_digit((int32_t)((uint32_t)c[i] & DMASK));
+        c[i + 1] += (c[i] >> WB) - lo * (int64_t)P252_P29_1;
+        if (i + 2 < NL + NDIG) c[i + 2] -= lo * (int64_t)P252_P29_2;
+        if (i + 3 < NL + NDIG) c[i + 3] -= lo * (int64_t)P252_P29_3;
+        if (i + 4 < NL + NDIG) c[i + 4] -= lo * (int64_t)P252_P29_4;
+        if (i + 5 < NL + NDIG) c[i + 5] -= lo * (int64_t)P252_P29_5;
+        if (i + 6 < NL + NDIG) c[i + 6] -= lo * (int64_t)P252_P29_6;
+        if (i + 7 < NL + NDIG) c[i + 7] -= lo * (int64_t)P252_P29_7;
+        if (i + 8 < NL + NDIG) c[i + 8] -= lo * (int64_t)P252_P29_8;
+    }
+    E29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = c[NDIG + k] + carry;
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
+        carry = v >> WB;
+    }
+    r.d[NL - 1] = opaque_digit((int32_t)(c[NL + NDIG - 1] + carry));
     A29 t;
     acc_set_hi_c(t, add);
-#pragma unroll
-    for (int j = 0; j < TERMS; ++j) acc_mul(t, *x[j], mul[j]);
+    acc_mul(t, r, fix);
     return redc(t);
+}
+
+// x * m + add for a small integer m (W_0 = 28 X_4 + const): nine products and a carry chain, no reduction —
+// the result is a 9-digit value below 2^260, used only as a multiplicand of one-digit products.
+template <class TP>
+P252_HD E29 small_mul_add(const E29& x, int32_t m, TP add) {
+    E29 r;
+    int64_t carry = 0;
+    const int64_t mm = m;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = (int64_t)x.d[k] * mm + (int64_t)add[k] + carry;
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
+        carry = v >> WB;
+    }
+    r.d[NL - 1] = opaque_digit((int32_t)((int64_t)x.d[NL - 1] * mm + (int64_t)add[NL - 1] + carry));
+    return r;
 }
 
 // Loop nest: two halves, each = four full rounds (one copy of that body in the instruction stream), the first half
 // followed by the partial phase: 12 iterations of HIST = 5 ARMA rounds in a loop of their own (its loop-carried
-// values are exactly the two history rings), then the exit rows (exit_row).  Full round 3 is the entry: lanes 0..3 of its linear
-// layer are the generic rows of the virtual history.  OUT_ROWS: bit k set = lane k of the result is needed (a
+// values are exactly the two history rings), then the exit rows (exit_row).  Full round 3 is the entry: its linear
+// layer produces U_1 and the virtual history (entry_row, small_mul_add).  OUT_ROWS: bit k set = lane k of the result is needed (a
 // Merkle4 digest needs lane 1 only: the multiplication by F is done for that lane alone).
 template <unsigned OUT_ROWS = 0x1fu, class TP>
 P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
@@ -272,21 +323,14 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
 #pragma unroll
             for (int j = 0; j < WIDTH; ++j) x[j] = sbox(s[j]);
             if (f == RF - 1) {
-                const E29* const xs[WIDTH] = {&x[0], &x[1], &x[2], &x[3], &x[4]};
-                E29 th[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const TP mul[WIDTH] = {tab + Lay::AI_ENT_MUL + (i * WIDTH + 0) * NL, tab + Lay::AI_ENT_MUL + (i * WIDTH + 1) * NL,
-                                           tab + Lay::AI_ENT_MUL + (i * WIDTH + 2) * NL, tab + Lay::AI_ENT_MUL + (i * WIDTH + 3) * NL,
-                                           tab + Lay::AI_ENT_MUL + (i * WIDTH + 4) * NL};
-                    th[i] = gen_row<WIDTH>(xs, mul, tab + Lay::AI_ENT_ADD + i * NL);
-                }
                 Us[1] = int_row(x, tab + Lay::INT_N + 4, kap + 4 * NL);  // U_1
-                Us[0] = th[0];                                           // U_0, U_-1, U_-2: virtual
-                Us[HIST - 1] = th[1];
-                Us[HIST - 2] = th[2];
+                // U_0, U_-1, U_-2: virtual
+                Us[0] = entry_row<1>(x, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD);
+                Us[HIST - 1] = entry_row<1>(x, tab + Lay::AI_ENT_N + NL, tab + Lay::AI_ENT_FIX + NL, tab + Lay::AI_ENT_ADD + NL);
+                Us[HIST - 2] = entry_row<2>(x, tab + Lay::AI_ENT_N + 2 * NL, tab + Lay::AI_ENT_FIX + 2 * NL, tab + Lay::AI_ENT_ADD + 2 * NL);
                 Us[2] = e29_zero();                                      // (free slot)
-                Ws[0] = th[3];                                           // W_0: virtual; W_-1, W_-2, W_-3 = 0
+                // W_0: virtual, = the lane-4 S-box output at the W scale (28 = 13 D / K); W_-1, W_-2, W_-3 = 0
+                Ws[0] = small_mul_add(x[4], ENTRY_W0_INT, tab + Lay::AI_ENT_ADD + 3 * NL);
 #pragma unroll
                 for (int i = 1; i < HIST; ++i) Ws[i] = e29_zero();
             } else {

@@ -45,7 +45,7 @@ size_t ht_tables_raw(uint64_t* out) {
     return k;
 }
 
-// integer-ARMA constants (residues, canonical words): ai_kappa[8][5], ent_mul[4][5], ent_add[4], then per round
+// integer-ARMA constants (residues, canonical words): ai_kappa[8][5], ent_fix[3], ent_add[4], then per round
 // q = 1..60: K_{q+1}, G_q; ex_fix[4], ex_add[4], F.  Returns the count, or 0 when mds.bin lacks the structure.
 size_t ht_tables_armaint_raw(uint64_t* out) {
     HadesTables T;
@@ -54,7 +54,7 @@ size_t ht_tables_armaint_raw(uint64_t* out) {
     size_t k = 0;
     auto put = [&](const FrHost& v) { v.to_canonical(out + 4 * k++); };
     for (int f = 0; f < 8; ++f) for (int i = 0; i < 5; ++i) put(T.ai_kappa[f][i]);
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) put(T.ai_ent_mul[i][j]);
+    for (int i = 0; i < 3; ++i) put(T.ai_ent_fix[i]);
     for (int i = 0; i < 4; ++i) put(T.ai_ent_add[i]);
     for (int q = 0; q < 60; ++q) { put(T.ai_k[q]); put(T.ai_g[q]); }
     for (int i = 0; i < 4; ++i) put(T.ai_ex_fix[i]);

@@ -48,6 +48,13 @@ constexpr int64_t EXIT_NV_INT[4][4] = {{34804924LL, -60095168892LL, 478555604051
                                        {571743634LL, -987190198929LL, 7863736475042LL, -532253038680LL},
                                        {4361446936LL, -7530617199006LL, 60001569615953LL, -4178036642670LL},
                                        {450277058LL, -777463806933LL, 6195760216744LL, -441369753660LL}};
+// Entry rows: the virtual history (u_0, u_-1, u_-2) as integer combinations of the S-box outputs 0..3 of full round 3
+// (times a generic factor per row; lane 4 does not enter), and v_0 = the lane-4 S-box output itself (W_0 = 28 X_4).
+constexpr int64_t ENTRY_N_INT[3][4] = {{-35LL, 252LL, -630LL, 660LL},
+                                       {-14040740LL, 66398598LL, -98452620LL, 46450965LL},
+                                       {-2121912819635LL, 9983493173052LL, -14744906064630LL, 6935043456660LL}};
+constexpr int ENTRY_DIGITS[3] = {1, 1, 2};
+constexpr int32_t ENTRY_W0_INT = 28;  // = 13 D / K
 
 struct SparseRound {
     FrHost w[4];    // row 4 of M''_q, columns 0..3
@@ -76,8 +83,8 @@ struct HadesTables {
     bool int_ok;                          // mds.bin really is R/(i+j+5), and ARMA_*_INT match it
     // ---- (C) integer ARMA: residues as the device holds them ----
     FrHost ai_kappa[FULL_ROUNDS][WIDTH];  // integer rows of the full rounds f = 0..7 (f = 3: lane 4 only)
-    FrHost ai_ent_mul[4][WIDTH];          // entry: virtual history (U_0, U_-1, U_-2, W_0) = generic rows of round 3's S-box outputs
-    FrHost ai_ent_add[4];
+    FrHost ai_ent_fix[3];                 // entry: the one generic product of each virtual-history row (U_0, U_-1, U_-2)
+    FrHost ai_ent_add[4];                 //        additive constants of U_0, U_-1, U_-2, W_0
     FrHost ai_k[PARTIAL_ROUNDS];          // K_{q+1} at [q-1], q = 1..60
     FrHost ai_g[PARTIAL_ROUNDS];          // G_q at [q-1]
     FrHost ai_ex_fix[4];                  // exit rows: 2^58 R' / den_i (the one generic product of an exit row)
@@ -420,10 +427,23 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
                 FrHost hc = th0[i];
                 for (int t = 0; t < WIDTH; ++t) hc = hc + H[i][t] * C[RF][t];
                 T.ai_ent_add[i] = tscale[i] * hc;
+                FrHost gen[WIDTH];  // generic form of the row: coefficient * R'
                 for (int j = 0; j < WIDTH; ++j) {
                     FrHost hm = FrHost::zero();
                     for (int t = 0; t < WIDTH; ++t) hm = hm + H[i][t] * M[t][j];
-                    T.ai_ent_mul[i][j] = tscale[i] * hm * e3inv * RP;
+                    gen[j] = tscale[i] * hm * e3inv * RP;
+                }
+                // integer form (hades29.hpp::entry_row): theta_i = (sum_j n_ij X_j) / 2^(29 digits_i) * fix_i / R' + add_i
+                if (i < 3) {
+                    const FrHost shift = FrHost::pow2(29u * (unsigned)ENTRY_DIGITS[i]);
+                    T.ai_ent_fix[i] = gen[0] * shift * fr_from_i64(ENTRY_N_INT[i][0]).inv();
+                    for (int j = 0; j < 4; ++j)
+                        if (!(gen[j] * shift == T.ai_ent_fix[i] * fr_from_i64(ENTRY_N_INT[i][j]))) T.int_ok = false;
+                    if (!gen[4].is_zero()) T.int_ok = false;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (!gen[j].is_zero()) T.int_ok = false;
+                    if (!(gen[4] == RP * FrHost::from_u64((uint64_t)ENTRY_W0_INT))) T.int_ok = false;
                 }
             }
         }
@@ -468,8 +488,9 @@ struct Tab29Layout {
     static constexpr int INT_N = C_FIRST + WIDTH * NL;                  // [9] ints: N[i][j] = h[i+j], h[d] = L/(d+5)
     static constexpr int AI_AB = INT_N + NL;                            // [9] ints: A_1..A_4, B_0..B_4
     static constexpr int AI_KAPPA = AI_AB + NL;                         // [8][5][9] raw
-    static constexpr int AI_ENT_MUL = AI_KAPPA + FULL_ROUNDS * WIDTH * NL;  // [4][5][9] raw
-    static constexpr int AI_ENT_ADD = AI_ENT_MUL + 4 * WIDTH * NL;      // [4][9] raw
+    static constexpr int AI_ENT_N = AI_KAPPA + FULL_ROUNDS * WIDTH * NL;  // [3][9] ints: 4 two-digit coefficients (lo, hi) + 1 pad per row
+    static constexpr int AI_ENT_FIX = AI_ENT_N + 3 * NL;                // [3][9] raw
+    static constexpr int AI_ENT_ADD = AI_ENT_FIX + 3 * NL;              // [4][9] raw
     static constexpr int AI_KG = AI_ENT_ADD + 4 * NL;                   // [60][2][9] raw: K_{q+1}, G_q per round (contiguous)
     static constexpr int AI_EX_N = AI_KG + PARTIAL_ROUNDS * 2 * NL;     // [4][18] ints: 8 two-digit coefficients (lo, hi) + 2 pad per row
     static constexpr int AI_EX_FIX = AI_EX_N + 4 * 2 * NL;              // [4][9] raw
@@ -540,16 +561,19 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
     for (int n = 0; n < 5; ++n) tab[Lay::AI_AB + 4 + n] = ARMA_B_INT[n];
     for (int f = 0; f < FULL_ROUNDS; ++f)
         for (int i = 0; i < WIDTH; ++i) put(Lay::AI_KAPPA + (f * WIDTH + i) * NL, T.ai_kappa[f][i], one);
+    auto split2 = [&](int off, int64_t n) {  // balanced two-digit split: n = lo + hi 2^29, |lo| <= 2^28
+        int64_t lo = n & (int64_t)DMASK;
+        if (lo > ((int64_t)1 << (WB - 1))) lo -= (int64_t)1 << WB;
+        tab[off] = (int32_t)lo;
+        tab[off + 1] = (int32_t)((n - lo) >> WB);
+    };
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j) split2(Lay::AI_ENT_N + i * NL + 2 * j, ENTRY_N_INT[i][j]);
+        put(Lay::AI_ENT_FIX + i * NL, T.ai_ent_fix[i], one);
+    }
     for (int i = 0; i < 4; ++i) {
-        for (int j = 0; j < WIDTH; ++j) put(Lay::AI_ENT_MUL + (i * WIDTH + j) * NL, T.ai_ent_mul[i][j], one);
         put(Lay::AI_ENT_ADD + i * NL, T.ai_ent_add[i], one);
-        for (int t = 0; t < 8; ++t) {  // balanced two-digit split: n = lo + hi 2^29, |lo| <= 2^28
-            const int64_t n = t < 4 ? EXIT_NY_INT[i][t] : EXIT_NV_INT[i][t - 4];
-            int64_t lo = n & (int64_t)DMASK;
-            if (lo > ((int64_t)1 << (WB - 1))) lo -= (int64_t)1 << WB;
-            tab[Lay::AI_EX_N + i * 2 * NL + 2 * t] = (int32_t)lo;
-            tab[Lay::AI_EX_N + i * 2 * NL + 2 * t + 1] = (int32_t)((n - lo) >> WB);
-        }
+        for (int t = 0; t < 8; ++t) split2(Lay::AI_EX_N + i * 2 * NL + 2 * t, t < 4 ? EXIT_NY_INT[i][t] : EXIT_NV_INT[i][t - 4]);
         put(Lay::AI_EX_FIX + i * NL, T.ai_ex_fix[i], one);
         put(Lay::AI_EX_ADD + i * NL, T.ai_ex_add[i], one);
     }
@@ -620,8 +644,13 @@ inline double max_column_bound29(const int32_t* tab) {
     group({Lay::INT_F});
     group({Lay::AI_F});
     for (int i = 0; i < 4; ++i) {
-        group({Lay::AI_ENT_MUL + (i * 5 + 0) * NL, Lay::AI_ENT_MUL + (i * 5 + 1) * NL, Lay::AI_ENT_MUL + (i * 5 + 2) * NL,
-               Lay::AI_ENT_MUL + (i * 5 + 3) * NL, Lay::AI_ENT_MUL + (i * 5 + 4) * NL});
+        if (i < 3) {
+            group({Lay::AI_ENT_FIX + i * NL});
+            double esum = 0;  // integer entry row: at most one digit product per coefficient digit per column, two digit steps
+            for (int t = 0; t < 8; ++t) esum += absd(tab[Lay::AI_ENT_N + i * NL + t]);
+            const double erow = DIG * esum + 2.0 * DIG * (double)P252_P29_1 + 68719476736.0;
+            if (erow > worst) worst = erow;
+        }
         group({Lay::AI_EX_FIX + i * NL});
         // integer exit row: a column collects at most one digit product per coefficient digit (16 of them), then six digit steps
         double nsum = 0;

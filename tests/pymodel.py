@@ -424,10 +424,44 @@ def _rational_arma():
         for x in cy + cv:
             den = lcm(den, x.denominator)
         ex.append((den, [int(x * den) for x in cy], [int(x * den) for x in cv]))
-    return [int(x) for x in Aint], [int(x) for x in Bint], ex
+    # entry rows: the virtual history (u_0, u_-1, u_-2, v_0) as a linear function of the S-box outputs of full round 3
+    # (constants aside).  Triangular solve of the q = 1..4 recurrence equations on the zero-input trajectory, all in
+    # exact fractions; v_0 turns out to be the lane-4 S-box output itself and the u rows are small integers over 495.
+    def resid(y1):
+        x, u = {1: list(y1[:4])}, {1: y1[4]}
+        for q in range(1, 5):
+            x[q + 1] = [sum(A[i][j] * x[q][j] for j in range(4)) for i in range(4)]
+            u[q + 1] = sum(c[j] * x[q][j] for j in range(4))
+        return [u[q + 1] - sum(a[m - 1] * u[q + 1 - m] for m in range(1, 5) if q + 1 - m >= 1) for q in range(1, 5)]
+    def solve(r):
+        v0 = r[3] / beta[4]
+        um0 = (r[2] - beta[3] * v0) / a[3]
+        um1 = (r[1] - beta[2] * v0 - a[2] * um0) / a[3]
+        um2 = (r[0] - beta[1] * v0 - a[1] * um0 - a[2] * um1) / a[3]
+        return [um0, um1, um2, v0]
+    Hm = [[None] * 5 for _ in range(4)]
+    for j in range(5):
+        e = [Fr(int(t == j)) for t in range(5)]
+        col = solve(resid(e))
+        for i in range(4):
+            Hm[i][j] = col[i]
+    HC = mm(Hm, C5)
+    assert HC[3] == [0, 0, 0, 0, 1]
+    from math import gcd
+    ent = []
+    for i in range(3):
+        den = 1
+        for x in HC[i]:
+            den = lcm(den, x.denominator)
+        nums = [int(x * den) for x in HC[i]]
+        g = 0
+        for x in nums:
+            g = gcd(g, abs(x))
+        ent.append([x // g for x in nums])
+    return [int(x) for x in Aint], [int(x) for x in Bint], ex, ent
 
 
-A_INT, B_INT, EXIT_INT = _rational_arma()   # [15104, -4729406, 18244864, -419265], [990, -1555121, 23296324, -2924911, 1694]
+A_INT, B_INT, EXIT_INT, ENTRY_INT = _rational_arma()   # [15104, -4729406, 18244864, -419265], [990, -1555121, 23296324, -2924911, 1694]
 
 
 def derive_armaint(C, M):
@@ -472,7 +506,7 @@ def derive_armaint(C, M):
         for i in range(4):
             H[i][j] = col[i]
     # ---- scales ----
-    out = dict(c_first=[c * RM % P for c in C[0]], fr_kappa={}, ent_mul=None, ent_add=None, K={}, G={}, ex_fix=None, ex_add=None)
+    out = dict(c_first=[c * RM % P for c in C[0]], fr_kappa={}, ent_fix=None, ent_add=None, K={}, G={}, ex_fix=None, ex_add=None)
     i29 = inv(pow(2, 29, P))
     step = L_INT * inv(RM) % P * i29 % P
     s = RM
@@ -490,8 +524,18 @@ def derive_armaint(C, M):
             HM = [[sum(H[i][t] * M[t][j] for t in range(5)) % P for j in range(5)] for i in range(4)]
             hc = [(sum(H[i][t] * C[Rf][t] for t in range(5)) + th0[i]) % P for i in range(4)]
             tscale = [sig(0), sig(-1), sig(-2), omg(0)]
-            out["ent_mul"] = [[tscale[i] * HM[i][j] % P * inv(e) % P * RP % P for j in range(5)] for i in range(4)]   # "MP": coefficient * R'
+            gen = [[tscale[i] * HM[i][j] % P * inv(e) % P * RP % P for j in range(5)] for i in range(4)]   # generic form: coefficient * R'
             out["ent_add"] = [tscale[i] * hc[i] % P for i in range(4)]
+            # integer form: theta_i = (sum_j n_ij X_j) / 2^(29 steps_i) * fix_i / R' + add_i with steps = digits of the n_ij;
+            # W_0 = 28 X_4 + add_3 needs no generic product at all
+            out["ent_fix"] = []
+            for i in range(3):
+                steps = 1 if max(abs(v) for v in ENTRY_INT[i]) < 1 << 28 else 2
+                j0 = next(j for j in range(5) if ENTRY_INT[i][j])
+                fix = gen[i][j0] * pow(2, 29 * steps, P) % P * inv(ENTRY_INT[i][j0]) % P
+                assert all(gen[i][j] == fix * ENTRY_INT[i][j] % P * pow(i29, steps, P) % P for j in range(5))
+                out["ent_fix"].append(fix)
+            assert gen[3] == [0, 0, 0, 0, 28 * RP % P]
             out["fr_kappa"][k] = [0, 0, 0, 0, pow(2, 29, P) * s_next % P * C[Rf][4] % P]
         s = s_next
     for q in range(1, PARTIAL + 1):
@@ -530,7 +574,12 @@ def perm_armaint(x_mont, C=None, M=None, T=None):
         X = [sbox(z) for z in Z]
         Z = [irow(X, i, T["fr_kappa"][k][i]) for i in range(5)]
     X = [sbox(z) for z in Z]
-    th = [grow([(X[j], T["ent_mul"][i][j]) for j in range(5)], T["ent_add"][i]) for i in range(4)]
+    th = []
+    for i in range(3):
+        steps = 1 if max(abs(v) for v in ENTRY_INT[i]) < 1 << 28 else 2
+        acc = sum(ENTRY_INT[i][j] * X[j] for j in range(5)) * pow(i29, steps, P) % P
+        th.append(grow([(acc, T["ent_fix"][i])], T["ent_add"][i]))
+    th.append((28 * X[4] + T["ent_add"][3]) % P)
     U = {1: irow(X, 4, T["fr_kappa"][Rf - 1][4]), 0: th[0], -1: th[1], -2: th[2]}
     W = {0: th[3], -1: 0, -2: 0, -3: 0}
     i145 = pow(i29, 5, P)

@@ -93,7 +93,7 @@ def test_table_digit_bounds(hosttest_lib):
     assert n % 9 == 0 and np.abs(tab.astype(np.int64)).max() <= (1 << 28)
     digits = tab.reshape(-1, 9).astype(object)
     vals = [sum(int(d) << (29 * i) for i, d in enumerate(row)) for row in digits]
-    plain_ints = {5, 6} | set(range(191, 199))  # rows of one-digit integers (INT_N, AI_AB, AI_EX_N), not 9-digit residues
+    plain_ints = {5, 6} | set(range(47, 50)) | set(range(177, 185))  # rows of one-digit integers (INT_N, AI_AB, AI_EX_N), not 9-digit residues
     assert all(abs(v) <= P // 2 + 1 for k, v in enumerate(vals) if k not in plain_ints)
 
 
@@ -149,13 +149,13 @@ def test_integer_arma_tables_match_bigint_derivation(hosttest_lib):
     exact fractions for the integer coefficients, big ints for the residues), and the big-int model vs the reference"""
     C, M = pymodel.load_constants()
     T = pymodel.derive_armaint(C, M)
-    n = 40 + 20 + 4 + 120 + 4 + 4 + 1
+    n = 40 + 3 + 4 + 120 + 4 + 4 + 1
     raw = np.empty((n, 4), dtype=np.uint64)
     hosttest_lib.ht_tables_armaint_raw.restype = ctypes.c_size_t
     assert hosttest_lib.ht_tables_armaint_raw(p(raw)) == n
     fr = dict(T["fr_kappa"])
     exp = [fr[k][i] for k in (0, 1, 2, 3, 64, 65, 66, 67) for i in range(5)]
-    exp += [T["ent_mul"][i][j] for i in range(4) for j in range(5)] + list(T["ent_add"])
+    exp += list(T["ent_fix"]) + list(T["ent_add"])
     for q in range(1, 61):
         exp += [T["K"][q + 1], T["G"][q]]
     exp += list(T["ex_fix"]) + list(T["ex_add"]) + [T["F"]]
@@ -167,11 +167,14 @@ def test_integer_arma_tables_match_bigint_derivation(hosttest_lib):
     assert list(tab[45:54]) == [pymodel.L_INT // (d + 5) for d in range(9)]
     assert list(tab[54:63]) == pymodel.A_INT + pymodel.B_INT
     assert max(abs(v) for v in pymodel.A_INT + pymodel.B_INT) < 1 << 25
-    base = 63 + 8 * 45 + 4 * 45 + 4 * 9 + 60 * 18  # Tab29Layout::AI_EX_N
+    base = 63 + 8 * 45 + 3 * 9 + 3 * 9 + 4 * 9 + 60 * 18  # Tab29Layout::AI_EX_N
     for i, (den, ny, nv) in enumerate(pymodel.EXIT_INT):  # two-digit exit coefficients, balanced low digit
         row = [int(v) for v in tab[base + 18 * i: base + 18 * i + 16]]
         assert [row[2 * t] + (row[2 * t + 1] << 29) for t in range(8)] == ny + nv
         assert all(abs(row[2 * t]) <= 1 << 28 and abs(row[2 * t + 1]) < 1 << 18 for t in range(8))
+    for i, nums in enumerate(pymodel.ENTRY_INT):  # entry coefficients (lane 4 does not enter)
+        row = [int(v) for v in tab[63 + 8 * 45 + 9 * i: 63 + 8 * 45 + 9 * i + 8]]
+        assert [row[2 * t] + (row[2 * t + 1] << 29) for t in range(4)] == nums[:4] and nums[4] == 0
     rng = random.Random(6)
     for _ in range(2):
         x = [rng.randrange(P) for _ in range(5)]
