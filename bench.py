@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 # algorithmic figures
 MACS_PER_PERM_REFERENCE = 256_000      # 2000 field mults x 128 32x32->64 MACs (reference schedule)
 # v_mad_i64_i32 instructions one lane executes per Merkle4 digest with the integer-ARMA schedule:
-# 100 S-boxes x 387 + 60 x (153 G-product + 121 ARMA row) + 36 integer rows x 61 + entry 1,908 + exit 2,880 + F 153
-MACS_PER_PERM_EXECUTED = 62_277
+# 100 S-boxes x 387 + 60 x (153 G-product + 121 ARMA row) + 36 integer rows x 61 + entry 644 + exit 1,380 + F 153
+MACS_PER_PERM_EXECUTED = 59_513
 BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 12.0}
 # measured on MI355X by bench_tools/valu_rates.hip (profiles/r01_valu_rates_gfx950.txt):
 # v_mad_u64_u32 sustains 504.9 G wave-instructions/s chip-wide = 32.3e12 lane-MACs/s

@@ -65,6 +65,15 @@ P252_HD int32_t opaque_digit(int32_t x) {
     return x;
 }
 
+// Keeps the instruction scheduler from interleaving two large independent computations (e.g. successive rows of
+// the exit): interleaving buys no throughput here (the issue slots are full either way) but it keeps both
+// accumulator sets live, and the sponge-type kernels then exceed 256 VGPRs = drop to one wave per SIMD.
+P252_HD void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // 18 signed 64-bit columns: column k has weight 2^(29 k).
 struct A29 {
     int64_t c[2 * NL];

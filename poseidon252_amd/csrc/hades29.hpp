@@ -315,30 +315,37 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        E29 Us[HIST], Ws[HIST];
 #pragma unroll 1
         for (int f = half * RF; f < (half + 1) * RF; ++f) {
             const TP kap = tab + Lay::AI_KAPPA + f * WIDTH * NL;
             E29 x[WIDTH];
 #pragma unroll
             for (int j = 0; j < WIDTH; ++j) x[j] = sbox(s[j]);
-            if (f == RF - 1) {
-                Us[1] = int_row(x, tab + Lay::INT_N + 4, kap + 4 * NL);  // U_1
-                // U_0, U_-1, U_-2: virtual
-                Us[0] = entry_row<1>(x, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD);
-                Us[HIST - 1] = entry_row<1>(x, tab + Lay::AI_ENT_N + NL, tab + Lay::AI_ENT_FIX + NL, tab + Lay::AI_ENT_ADD + NL);
-                Us[HIST - 2] = entry_row<2>(x, tab + Lay::AI_ENT_N + 2 * NL, tab + Lay::AI_ENT_FIX + 2 * NL, tab + Lay::AI_ENT_ADD + 2 * NL);
-                Us[2] = e29_zero();                                      // (free slot)
-                // W_0: virtual, = the lane-4 S-box output at the W scale (28 = 13 D / K); W_-1, W_-2, W_-3 = 0
-                Ws[0] = small_mul_add(x[4], ENTRY_W0_INT, tab + Lay::AI_ENT_ADD + 3 * NL);
+            if (f == RF - 1) {  // the linear layer of round 3 is the entry below: hand over the S-box outputs
 #pragma unroll
-                for (int i = 1; i < HIST; ++i) Ws[i] = e29_zero();
+                for (int i = 0; i < WIDTH; ++i) s[i] = x[i];
             } else {
 #pragma unroll
                 for (int i = 0; i < WIDTH; ++i) s[i] = int_row(x, tab + Lay::INT_N + i, kap + i * NL);
             }
         }
         if (half == 0) {
+            // (the history rings are defined here, after the loop above, so that they are not carried through it)
+            E29 Us[HIST], Ws[HIST];
+            Us[1] = int_row(s, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + ((RF - 1) * WIDTH + 4) * NL);  // U_1
+            sched_fence();
+            // U_0, U_-1, U_-2: virtual
+            Us[0] = entry_row<1>(s, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD);
+            sched_fence();
+            Us[HIST - 1] = entry_row<1>(s, tab + Lay::AI_ENT_N + NL, tab + Lay::AI_ENT_FIX + NL, tab + Lay::AI_ENT_ADD + NL);
+            sched_fence();
+            Us[HIST - 2] = entry_row<2>(s, tab + Lay::AI_ENT_N + 2 * NL, tab + Lay::AI_ENT_FIX + 2 * NL, tab + Lay::AI_ENT_ADD + 2 * NL);
+            sched_fence();
+            Us[2] = e29_zero();  // (free slot)
+            // W_0: virtual, = the lane-4 S-box output at the W scale (28 = 13 D / K); W_-1, W_-2, W_-3 = 0
+            Ws[0] = small_mul_add(s[4], ENTRY_W0_INT, tab + Lay::AI_ENT_ADD + 3 * NL);
+#pragma unroll
+            for (int i = 1; i < HIST; ++i) Ws[i] = e29_zero();
 #pragma unroll 1
             for (int it = 0; it < PARTIAL_ROUNDS / HIST; ++it) {  // rounds q = 5 it + 1 .. 5 it + 5
                 const TP kg = tab + Lay::AI_KG + it * HIST * 2 * NL;
@@ -352,14 +359,19 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
             const E29* const us[4] = {&Us[3], &Us[4], &Us[0], &Us[1]};
             const E29* const ws[4] = {&Ws[2], &Ws[3], &Ws[4], &Ws[0]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
                 s[i] = exit_row(us, ws, tab + Lay::AI_EX_N + i * 2 * NL, tab + Lay::AI_EX_FIX + i * NL, tab + Lay::AI_EX_ADD + i * NL);
+                sched_fence();
+            }
             s[4] = Us[1];
         }
     }
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i)
-        if ((OUT_ROWS >> i) & 1u) s[i] = mul_c(s[i], tab + Lay::AI_F);
+        if ((OUT_ROWS >> i) & 1u) {
+            s[i] = mul_c(s[i], tab + Lay::AI_F);
+            sched_fence();
+        }
 }
 
 }  // namespace p252

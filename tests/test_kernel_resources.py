@@ -29,10 +29,14 @@ def test_no_scratch_and_register_budget(isa):
     names = re.findall(r"Function Name: (\S+)", remarks)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", remarks)]
     vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", remarks)]
-    assert len(names) >= 6 and len(scratch) == len(names) == len(vgprs)
-    for n, s, v in zip(names, scratch, vgprs):
+    agprs = [int(x) for x in re.findall(r"\bAGPRs: (\d+)", remarks)]
+    occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", remarks)]
+    assert len(names) >= 6 and len(scratch) == len(names) == len(vgprs) == len(agprs) == len(occ)
+    for n, s, v, a, o in zip(names, scratch, vgprs, agprs, occ):
         assert s == 0, "%s uses %d B of scratch per lane (an unroll fell back to a loop?)" % (n, s)
-        assert v <= 256, "%s needs %d VGPRs: below 2 waves/SIMD" % (n, v)
+        # 256 VGPRs + spills into AGPRs = one wave per SIMD: measured -18 % on the sponge kernel (the scheduler had
+        # interleaved independent rows and carried the history rings through the full-round loop)
+        assert a == 0 and v < 256 and o >= 2, "%s: %d VGPRs + %d AGPRs, %d waves/SIMD" % (n, v, a, o)
 
 
 def test_code_size_fits_instruction_cache_phases(isa):
