@@ -134,5 +134,15 @@ size_t ht_tables_int_raw(uint64_t* out) {
     return k;
 }
 
+// 1 when derive_tables accepts the built-in assets; with tweak != 0 one byte of a COPY of mds.bin is changed first
+// (entry tweak-1 of the matrix): the integer schedules must then be refused (int_ok = false -> p252_create fails).
+int ht_int_ok(int tweak) {
+    std::vector<unsigned char> mds(MDS_BIN, MDS_BIN + 25 * 32);
+    if (tweak > 0 && tweak <= 25) mds[(size_t)(tweak - 1) * 32] ^= 1;
+    HadesTables T;
+    derive_tables(ARC_BIN, mds.data(), T);
+    return T.int_ok ? 1 : 0;
+}
+
 double ht_max_column_bound29() { return max_column_bound29(tab29().data()); }
 }

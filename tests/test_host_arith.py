@@ -181,6 +181,14 @@ def test_integer_arma_tables_match_bigint_derivation(hosttest_lib):
         assert pymodel.perm_armaint([v * pymodel.RM % P for v in x], C, M, T) == [v * pymodel.RM % P for v in pymodel.perm_reference(x, C, M)]
 
 
+def test_integer_schedules_refuse_a_non_cauchy_mds(hosttest_lib):
+    """the kernels' schedule exists only because mds.bin is R/(i+j+5); derive_tables re-checks that (and the hard-coded
+    integer coefficients against the field values computed from the file) and the library refuses anything else"""
+    assert hosttest_lib.ht_int_ok(0) == 1
+    for entry in (1, 7, 13, 25):
+        assert hosttest_lib.ht_int_ok(entry) == 0
+
+
 def test_adversarial_noncanonical_limbs(oracle_mod, hosttest_lib):
     """inputs the reference would never produce (limbs >= p, all-ones, digit-saturating patterns): the device
     code treats the 256-bit pattern V as an integer, so the result must be the permutation of V * R^-1 mod p —
