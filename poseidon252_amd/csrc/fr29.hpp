@@ -100,17 +100,6 @@ P252_HD void acc_set_hi_c(A29& t, CP c) {
         t.c[NL + k] = c[k];
     }
 }
-// t += x * R'  — the "free" multiplication by the constant tau whose encoding is exactly 2^261
-P252_HD void acc_add_hi(A29& t, const E29& x) {
-#pragma unroll
-    for (int k = 0; k < NL; ++k) t.c[NL + k] += x.d[k];
-}
-template <class CP>
-P252_HD void acc_add_hi_c(A29& t, CP c) {
-#pragma unroll
-    for (int k = 0; k < NL; ++k) t.c[NL + k] += c[k];
-}
-
 // t += a * b, b = 9 digits readable as b[j] (constant-table pointer or E29::d)
 template <class BP>
 P252_HD void acc_mul(A29& t, const E29& a, BP b) {
