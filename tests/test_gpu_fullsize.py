@@ -54,6 +54,19 @@ def test_config2_scaled_up_2pow24_digests(gpu_ctx, oracle_mod):
     assert torch.equal(d_out2, d_out[lo:lo + 4096])
 
 
+def test_config2_every_digest_against_the_oracle(gpu_ctx, oracle_mod):
+    """configs[1] in full: all 2^20 Merkle4 digests of the seeded batch, limb for limb against the CPU restatement of the
+    reference schedule (multi-threaded: a few seconds) — not a sample"""
+    import os
+    n = 1 << 20
+    tag = oracle_mod.tag(0, [4], 1)
+    h = oracle_mod.fill_random(0xc10d, 4 * n).reshape(n, 4, 4)
+    got = gpu_ctx.hash_batch(tag, h, 4, 1).reshape(n, 4)
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    exp = oracle_mod.hash_batch(tag, h, 4, 1, threads=threads).reshape(n, 4)
+    assert np.array_equal(got, exp)
+
+
 def test_config4_full_2pow20_sponges(gpu_ctx, oracle_mod):
     """Domain::Other, 2^20 messages x 42 scalars -> 5 outputs (1.3 GiB in, 12 permutations each)"""
     import torch
