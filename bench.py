@@ -32,7 +32,8 @@ MACS_PER_PERM_REFERENCE = 256_000      # 2000 field mults x 128 32x32->64 MACs (
 # v_mad_i64_i32 instructions one lane executes per Merkle4 digest with the integer-ARMA schedule:
 # 100 S-boxes x 387 + 60 x (153 G-product + 121 ARMA row) + 36 integer rows x 61 + entry 644 + exit 1,380 + F 153
 MACS_PER_PERM_EXECUTED = 59_513
-BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 12.0}
+BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 12.0,
+                  "openings": (32 + 12 * 96 + 12 + 32) / 12.0}  # leaf + 12 x 3 siblings + 12 position bytes + root
 # measured on MI355X by bench_tools/valu_rates.hip (profiles/r01_valu_rates_gfx950.txt):
 # v_mad_u64_u32 sustains 504.9 G wave-instructions/s chip-wide = 32.3e12 lane-MACs/s
 PEAK_INT32_MAC_PER_S = 504.9e9 * 64
@@ -44,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # the clocks need ~10 launches (25 ms) to ramp from idle
-    ap.add_argument("--workload", default="merkle4_digests", choices=["merkle4_digests", "tree", "sponge42"])
+    ap.add_argument("--workload", default="merkle4_digests", choices=["merkle4_digests", "tree", "sponge42", "openings"])
     ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step (default: 20; tree: 24 leaves)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -170,7 +171,12 @@ def cpu_baseline(tag, gpu_sample=None):
     parity = None
     if gpu_sample is not None:
         kind, inp, in_len, out_len, got = gpu_sample
-        exp = oracle.merkle4_tree(tag, inp)[0] if kind == "tree" else oracle.hash_batch(tag, inp, in_len, out_len)
+        if kind == "tree":
+            exp = oracle.merkle4_tree(tag, inp)[0]
+        elif kind == "paths":
+            exp = oracle.merkle4_path_batch(tag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
+        else:
+            exp = oracle.hash_batch(tag, inp, in_len, out_len)
         parity = bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(exp).reshape(-1)))
     return {"parity_sample_ok": parity,
             "value": nall / best, "unit": "permutations/s", "cores": threads, "kind": "port",
@@ -229,6 +235,13 @@ def main():
         hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
         in_scalars, perms_per_step = n, P.levels_len(n)
         name = "2^%d-leaf arity-4 Merkle tree per GPU, all levels (BASELINE configs[2])" % log2n
+    elif wl == "openings":
+        log2n = args.log2n or 20
+        n = 1 << log2n
+        depth = 12
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        in_scalars, perms_per_step = n * (1 + 3 * depth), depth * n
+        name = "2^%d Merkle4 openings of depth %d per GPU (branch re-hash, SURVEY §8 f3)" % (log2n, depth)
     else:
         log2n = args.log2n or 20
         n = 1 << log2n
@@ -263,6 +276,11 @@ def main():
             perms_per_step += P.levels_len(world)
             name += " + all-gather of %d subtree roots and top levels" % world
         step()  # allocate the context-owned level scratch outside the timed region
+    elif wl == "openings":
+        d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        d_leaves, d_sibs = d_in[:n], d_in[n:]
+        d_pos = torch.randint(0, 4, (n, depth), dtype=torch.uint8, device=dev, generator=g)
+        step = lambda: ctx.merkle4_path_batch_device(tag, d_leaves, d_sibs, d_pos, depth, d_out, n)
     else:
         d_out = torch.empty((n, 5, 4), dtype=torch.int64, device=dev)
         step = lambda: ctx.hash_batch_device(tag, d_in, 42, 5, d_out, n)
@@ -307,6 +325,13 @@ def main():
             ctx.merkle4_tree_device(tag, d_in, n, ref, None)
             torch.cuda.synchronize()
             self_ok = bool(torch.equal(top, ref))
+        elif wl == "openings":
+            lo, cnt = n // 3, min(n - n // 3, 4096)
+            again = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
+            ctx.merkle4_path_batch_device(tag, d_leaves[lo:lo + cnt], d_sibs[lo * 3 * depth:(lo + cnt) * 3 * depth], d_pos[lo:lo + cnt].contiguous(),
+                                          depth, again, cnt)
+            torch.cuda.synchronize()
+            self_ok = bool(torch.equal(again, d_out[lo:lo + cnt]))
         else:
             lo, cnt = n // 3, min(n - n // 3, 1024)
             again = torch.empty((cnt, 5, 4), dtype=torch.int64, device=dev)
@@ -333,7 +358,7 @@ def main():
             "config": {"workload": name, "units_per_gpu_per_step": perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
                        "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
             "roofline": {
-                "bound": "valu-int32-mac", "kernel": "k_merkle4" if wl != "sponge42" else "k_sponge",
+                "bound": "valu-int32-mac", "kernel": {"sponge42": "k_sponge", "openings": "k_merkle4_path"}.get(wl, "k_merkle4"),
                 "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
                 "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
                 "note": "algorithmic MACs = 256,000 per permutation (reference schedule, SURVEY §8d) x permutations per launch / mean launch time "
@@ -366,6 +391,10 @@ def main():
                     sub = 1 << 12
                     got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
                     sample = ("tree", h_in[:sub], None, None, got)
+                elif wl == "openings":
+                    idx = np.arange(0, n, max(1, n // 128))
+                    sample = ("paths", (h_in[:n][idx], h_in[n:].reshape(n, depth, 3, 4)[idx], d_pos.cpu().numpy()[idx]), None, None,
+                              d_out.cpu().numpy().view(np.uint64)[idx])
                 else:
                     idx = np.arange(0, n, max(1, n // 128))
                     sample = ("hash", h_in.reshape(n, 42, 4)[idx], 42, 5, d_out.cpu().numpy().view(np.uint64).reshape(n, 5, 4)[idx])

@@ -54,6 +54,19 @@ def test_bench_cpu_baseline_leg_checks_gpu_sample(gpu_ctx):
     assert d["self_consistency_ok"] is True
 
 
+@pytest.mark.parametrize("workload,log2n,kernel", [("sponge42", "12", "k_sponge"), ("openings", "12", "k_merkle4_path"), ("tree", "14", "k_merkle4")])
+def test_bench_other_workloads(gpu_ctx, workload, log2n, kernel):
+    """the non-default workloads (configs[2], configs[3], the openings of SURVEY §8 f3): same contract, self-consistency
+    and the oracle check of a sample of what was timed"""
+    oracle_leg = workload == "openings"  # the cpu_baseline leg costs ~25 s: once for the sample kind no other test covers
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", workload,
+                                   "--log2n", log2n] + ([] if oracle_leg else ["--no-cpu-baseline"]),
+                                  cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
+    d = _one_json_line(out)
+    assert d["self_consistency_ok"] is True and (not oracle_leg or d["cpu_baseline"]["parity_sample_ok"] is True)
+    assert d["roofline"]["kernel"] == kernel and d["value"] > 1e5
+
+
 def test_bench_rccl_backend_single_rank(gpu_ctx):
     """the real nccl (= RCCL) process group on the GPU: init, table broadcast, barrier, all-reduce —
     one rank is all a 1-GPU box allows, but it is the same code path the 8-GPU run takes"""
