@@ -33,7 +33,8 @@ MACS_PER_PERM_REFERENCE = 256_000      # 2000 field mults x 128 32x32->64 MACs (
 # 100 S-boxes x 387 + 60 x (153 G-product + 121 ARMA row) + 36 integer rows x 61 + entry 644 + exit 1,380 + F 153
 MACS_PER_PERM_EXECUTED = 59_513
 BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 12.0,
-                  "openings": (32 + 12 * 96 + 12 + 32) / 12.0}  # leaf + 12 x 3 siblings + 12 position bytes + root
+                  "openings": (32 + 12 * 96 + 12 + 32) / 12.0,  # leaf + 12 x 3 siblings + 12 position bytes + root
+                  "encrypt": (5 * 32 + 3 * 32) / 2.0}             # 2 message + 2 secret + 1 nonce scalars in, 3 cipher scalars out
 # measured on MI355X by bench_tools/valu_rates.hip (profiles/r01_valu_rates_gfx950.txt):
 # v_mad_u64_u32 sustains 504.9 G wave-instructions/s chip-wide = 32.3e12 lane-MACs/s
 PEAK_INT32_MAC_PER_S = 504.9e9 * 64
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # the clocks need ~10 launches (25 ms) to ramp from idle
-    ap.add_argument("--workload", default="merkle4_digests", choices=["merkle4_digests", "tree", "sponge42", "openings"])
+    ap.add_argument("--workload", default="merkle4_digests", choices=["merkle4_digests", "tree", "sponge42", "openings", "encrypt"])
     ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step (default: 20; tree: 24 leaves)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -173,6 +174,8 @@ def cpu_baseline(tag, gpu_sample=None):
         kind, inp, in_len, out_len, got = gpu_sample
         if kind == "tree":
             exp = oracle.merkle4_tree(tag, inp)[0]
+        elif kind == "encrypt":
+            exp = oracle.encrypt_batch(tag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
         elif kind == "paths":
             exp = oracle.merkle4_path_batch(tag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
         else:
@@ -235,6 +238,12 @@ def main():
         hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
         in_scalars, perms_per_step = n, P.levels_len(n)
         name = "2^%d-leaf arity-4 Merkle tree per GPU, all levels (BASELINE configs[2])" % log2n
+    elif wl == "encrypt":
+        log2n = args.log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)  # (only for the context; the tag below is the encryption tag)
+        in_scalars, perms_per_step = 5 * n, 2 * n
+        name = "2^%d encryptions of 2-scalar messages per GPU (2 permutations each, SURVEY §8 f4; recipe unpinned)" % log2n
     elif wl == "openings":
         log2n = args.log2n or 20
         n = 1 << log2n
@@ -249,6 +258,9 @@ def main():
         in_scalars, perms_per_step = 42 * n, 12 * n
         name = "Domain::Other sponge, 2^%d messages x 42 scalars -> 5 outputs per GPU (BASELINE configs[3])" % log2n
     tag = hb.tag
+    if wl == "encrypt":
+        from poseidon252_amd import encryption as E
+        tag = E.encryption_tag(2)
 
     # synthetic input generated ON the device (splitmix64-like hash of the index, top bits cleared so
     # every scalar is < 2^254 < p: a valid Montgomery residue; the permutation cost is data-independent)
@@ -276,6 +288,10 @@ def main():
             perms_per_step += P.levels_len(world)
             name += " + all-gather of %d subtree roots and top levels" % world
         step()  # allocate the context-owned level scratch outside the timed region
+    elif wl == "encrypt":
+        d_out = torch.empty((n, 3, 4), dtype=torch.int64, device=dev)
+        d_msgs, d_secrets, d_nonces = d_in[:2 * n], d_in[2 * n:4 * n], d_in[4 * n:]
+        step = lambda: E.encrypt_batch_device(d_msgs, d_secrets, d_nonces, 2, d_out, n, ctx=ctx, tag=tag)
     elif wl == "openings":
         d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
         d_leaves, d_sibs = d_in[:n], d_in[n:]
@@ -325,6 +341,13 @@ def main():
             ctx.merkle4_tree_device(tag, d_in, n, ref, None)
             torch.cuda.synchronize()
             self_ok = bool(torch.equal(top, ref))
+        elif wl == "encrypt":
+            # decrypting what was just produced gives the messages back, with every authentication flag set
+            back = torch.empty((n, 2, 4), dtype=torch.int64, device=dev)
+            ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+            E.decrypt_batch_device(d_out, d_secrets, d_nonces, 2, back, ok, n, ctx=ctx, tag=tag)
+            torch.cuda.synchronize()
+            self_ok = bool(torch.equal(back.view(-1, 4), d_msgs) and bool(ok.all()))
         elif wl == "openings":
             lo, cnt = n // 3, min(n - n // 3, 4096)
             again = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
@@ -358,7 +381,7 @@ def main():
             "config": {"workload": name, "units_per_gpu_per_step": perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
                        "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
             "roofline": {
-                "bound": "valu-int32-mac", "kernel": {"sponge42": "k_sponge", "openings": "k_merkle4_path"}.get(wl, "k_merkle4"),
+                "bound": "valu-int32-mac", "kernel": {"sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}.get(wl, "k_merkle4"),
                 "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
                 "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
                 "note": "algorithmic MACs = 256,000 per permutation (reference schedule, SURVEY §8d) x permutations per launch / mean launch time "
@@ -391,6 +414,10 @@ def main():
                     sub = 1 << 12
                     got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
                     sample = ("tree", h_in[:sub], None, None, got)
+                elif wl == "encrypt":
+                    idx = np.arange(0, n, max(1, n // 128))
+                    sample = ("encrypt", (h_in[:2 * n].reshape(n, 2, 4)[idx], h_in[2 * n:4 * n].reshape(n, 2, 4)[idx], h_in[4 * n:][idx]), None, None,
+                              d_out.cpu().numpy().view(np.uint64)[idx])
                 elif wl == "openings":
                     idx = np.arange(0, n, max(1, n // 128))
                     sample = ("paths", (h_in[:n][idx], h_in[n:].reshape(n, depth, 3, 4)[idx], d_pos.cpu().numpy()[idx]), None, None,

@@ -81,3 +81,27 @@ def decrypt(cipher, shared_secret, nonce, ctx=None, tag=None):
     if not ok[0]:
         raise DecryptionFailed("DecryptionFailed")
     return msg[0]
+
+
+def encrypt_batch_device(d_messages, d_secrets, d_nonces, message_len, d_ciphers, n, ctx=None, tag=None):
+    """device-resident variant (torch CUDA tensors of int64 limbs): messages n*len, secrets n*2, nonces n scalars in,
+    ciphers n*(len+1) scalars out; asynchronous on torch's current stream"""
+    import torch
+    ctx = ctx or Context.default()
+    tag = encryption_tag(message_len) if tag is None else _as_scalars(tag).reshape(4)
+    assert all(t.is_cuda for t in (d_messages, d_secrets, d_nonces, d_ciphers))
+    assert d_ciphers.numel() * d_ciphers.element_size() >= n * (message_len + 1) * 32
+    ctx._check(_lib.lib().p252_encrypt_batch_device(ctx._h, tag.ctypes.data_as(_u64p), d_messages.data_ptr(), d_secrets.data_ptr(),
+                                                    d_nonces.data_ptr(), message_len, d_ciphers.data_ptr(), n,
+                                                    torch.cuda.current_stream().cuda_stream))
+
+
+def decrypt_batch_device(d_ciphers, d_secrets, d_nonces, message_len, d_messages, d_ok, n, ctx=None, tag=None):
+    """device-resident variant: d_ok is a uint8 tensor of n flags (0 = DecryptionFailed for that item)"""
+    import torch
+    ctx = ctx or Context.default()
+    tag = encryption_tag(message_len) if tag is None else _as_scalars(tag).reshape(4)
+    assert all(t.is_cuda for t in (d_ciphers, d_secrets, d_nonces, d_messages, d_ok)) and d_ok.numel() >= n
+    ctx._check(_lib.lib().p252_decrypt_batch_device(ctx._h, tag.ctypes.data_as(_u64p), d_ciphers.data_ptr(), d_secrets.data_ptr(),
+                                                    d_nonces.data_ptr(), message_len, d_messages.data_ptr(), d_ok.data_ptr(), n,
+                                                    torch.cuda.current_stream().cuda_stream))

@@ -54,7 +54,8 @@ def test_bench_cpu_baseline_leg_checks_gpu_sample(gpu_ctx):
     assert d["self_consistency_ok"] is True
 
 
-@pytest.mark.parametrize("workload,log2n,kernel", [("sponge42", "12", "k_sponge"), ("openings", "12", "k_merkle4_path"), ("tree", "14", "k_merkle4")])
+@pytest.mark.parametrize("workload,log2n,kernel", [("sponge42", "12", "k_sponge"), ("openings", "12", "k_merkle4_path"), ("tree", "14", "k_merkle4"),
+                                                   ("encrypt", "12", "k_crypt")])
 def test_bench_other_workloads(gpu_ctx, workload, log2n, kernel):
     """the non-default workloads (configs[2], configs[3], the openings of SURVEY §8 f3): same contract, self-consistency
     and the oracle check of a sample of what was timed"""
