@@ -4,7 +4,6 @@ import ctypes
 import random
 
 import numpy as np
-import pytest
 
 import pymodel
 
