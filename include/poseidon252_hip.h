@@ -21,6 +21,8 @@
  * computed by the real dusk crates; p252_tag() is a host convenience whose byte-level recipe is
  * not covered by any reference test ("parity unpinned").
  *
+ * Device-resident (`*_device`) scalar arrays must be 16-byte aligned (any hipMalloc'ed BlsScalar array, or a
+ * whole-scalar offset into one, is); a misaligned pointer returns P252_ERR_INVALID_ARGUMENT.
  * Errors: functions return 0 on success or a negative P252_ERR_*; nothing unwinds across the
  * boundary.  Where the reference panics (Hash::finalize on an invalid io-pattern, hash.rs:124-137)
  * this library returns P252_ERR_IO_PATTERN_VIOLATION / P252_ERR_INVALID_IO_PATTERN and the host

@@ -3,6 +3,7 @@
 // launch sequencing.  All hashing runs in kernels.hip; there is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,11 @@ static const std::vector<int32_t>& host_tables() {
     }();
     return tab;
 }
+
+// device-resident scalar arrays are read and written with 16-byte accesses (a BlsScalar array from hipMalloc, or any
+// 32-byte-multiple offset into one, qualifies); anything else would fault on the GPU, so it is refused here
+static bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+static const char* const ALIGN_MSG = "device scalar arrays must be 16-byte aligned";
 
 static TagArg tag_arg(const uint64_t tag[4]) {
     TagArg t;
@@ -152,6 +158,7 @@ int p252_permute_batch_device(p252_ctx* ctx, const void* d_states, void* d_out, 
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (n == 0) return P252_OK;
     if (!d_states || !d_out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "permute: NULL buffer");
+    if (misaligned(d_states) || misaligned(d_out)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_permute(ctx->d_tab, d_states, d_out, n, (hipStream_t)hip_stream));
     return P252_OK;
@@ -167,6 +174,7 @@ int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_i
         return fail(ctx, P252_ERR_INVALID_ARGUMENT, "hash: length too large");
     if (n == 0) return P252_OK;
     if (!tag || !d_in || !d_out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "hash: NULL buffer");
+    if (misaligned(d_in) || misaligned(d_out)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (in_len == 4 && out_len == 1)
@@ -194,6 +202,7 @@ static int merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree: n_leaves must be > 0");
     if (!tag || !d_leaves || !d_root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree: NULL buffer");
+    if (misaligned(d_leaves) || misaligned(d_levels)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);  // d_root: plain copy
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     const TagArg t = tag_arg(tag);
@@ -379,6 +388,7 @@ int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_ra
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (n == 0) return P252_OK;
     if (!d_scalars || !d_out_raw) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "truncate250: NULL buffer");
+    if (misaligned(d_scalars) || misaligned(d_out_raw)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_truncate250(d_scalars, d_out_raw, n, (hipStream_t)hip_stream));
     return P252_OK;
@@ -391,6 +401,7 @@ int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const v
     if (!tag || !d_leaves || !d_roots || (depth && (!d_siblings || !d_positions)))
         return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: NULL buffer");
     if (depth > 0xffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: depth too large");
+    if (misaligned(d_leaves) || misaligned(d_roots) || (depth && misaligned(d_siblings))) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_merkle4_path(ctx->d_tab, tag_arg(tag), d_leaves, d_siblings, d_positions, (unsigned)depth,
                                      d_roots, n, (hipStream_t)hip_stream));
@@ -432,6 +443,7 @@ static int crypt_device(p252_ctx* ctx, bool decrypt, const uint64_t tag[4], cons
     if (n == 0) return P252_OK;
     if (!tag || !d_in || !d_secrets || !d_nonces || !d_out || (decrypt && !d_ok))
         return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: NULL buffer");
+    if (misaligned(d_in) || misaligned(d_secrets) || misaligned(d_nonces) || misaligned(d_out)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_crypt(decrypt, ctx->d_tab, tag_arg(tag), d_in, d_secrets, d_nonces, (unsigned)len, d_out, d_ok, n,
                               (hipStream_t)hip_stream));

@@ -104,6 +104,23 @@ def test_invalid_patterns_return_error_codes(gpu_ctx):
 
 
 # ---------------------------------------------------------------- Hash / HashBatch mirror (reads like tests/hash.rs + README)
+def test_misaligned_device_pointers_are_refused(gpu_ctx, oracle_mod):
+    """the kernels use 16-byte accesses: a device pointer 8 bytes off (a Rust BlsScalar is only 8-byte aligned, but a
+    device array of them never starts there) must come back as an error, not as a GPU fault"""
+    import torch
+    tag = oracle_mod.tag(0, [4], 1)
+    buf = torch.zeros(4 * 64 * 4 + 1, dtype=torch.int64, device="cuda")
+    out = torch.zeros(64 * 4 + 1, dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        gpu_ctx.hash_batch_device(tag, buf[1:], 4, 1, out, 64)
+    with pytest.raises(ValueError):
+        gpu_ctx.hash_batch_device(tag, buf, 4, 1, out[1:], 64)
+    with pytest.raises(ValueError):
+        gpu_ctx.permute_batch_device(buf[1:], buf, 32)
+    gpu_ctx.hash_batch_device(tag, buf[4:], 4, 1, out[4:], 63)  # whole-scalar offsets are fine
+    torch.cuda.synchronize()
+
+
 def test_hash_api_like_reference_tests(gpu_ctx, oracle_mod):
     import poseidon252_amd as P
     # tests/hash.rs shapes: 3 / 5 / 15 inputs, default output_len
