@@ -22,7 +22,8 @@
  * not covered by any reference test ("parity unpinned").
  *
  * Device-resident (`*_device`) scalar arrays must be 16-byte aligned (any hipMalloc'ed BlsScalar array, or a
- * whole-scalar offset into one, is); a misaligned pointer returns P252_ERR_INVALID_ARGUMENT.
+ * whole-scalar offset into one, is); a misaligned pointer returns P252_ERR_INVALID_ARGUMENT.  Input and output
+ * arrays of one call must not overlap unless a function says otherwise (inputs are only read, hash.rs:94,118-120).
  * Errors: functions return 0 on success or a negative P252_ERR_*; nothing unwinds across the
  * boundary.  Where the reference panics (Hash::finalize on an invalid io-pattern, hash.rs:124-137)
  * this library returns P252_ERR_IO_PATTERN_VIOLATION / P252_ERR_INVALID_IO_PATTERN and the host
