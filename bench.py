@@ -306,6 +306,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device wake-up (setup, reported in the JSON line): an idle MI355X needs ~25 ms of activity before its clocks
+    # reach the steady state a running service sees (profiles/r01_bench_kernel_trace_v9.txt: the first ten launches are up
+    # to 25 % slower).  Done here so that the measurement does not depend on how many warm-up steps the caller asks
+    # for; the W warm-up steps and the K timed steps below are untouched.
+    WAKE_UP_LAUNCHES = 24  # a fixed count (not a time): every rank must issue the same collectives at N > 1
+    for _ in range(WAKE_UP_LAUNCHES):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -400,6 +408,8 @@ def main():
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": hbm_gbps / PEAK_HBM_GBPS, "traffic": pmc_traffic(wl, perms_per_step)},
             "self_consistency_ok": self_ok,
+            "setup": {"wake_up_launches": WAKE_UP_LAUNCHES,
+                      "note": "untimed launches of the same step before the W warm-up steps: brings an idle GPU's clocks to steady state"},
         }
         if world == 1 and not args.no_cpu_baseline:
             # the cpu_baseline leg is the ONLY place bench.py touches oracle/: it times the CPU restatement and,
