@@ -8,7 +8,10 @@ A "step" is one pass of the hot path over one batch of synthetic input already r
 the default workload is BASELINE.json configs[1] — 2^20 independent Hash::digest(Domain::Merkle4,
 4 random BlsScalar) per GPU, one Hades permutation each, one kernel launch (k_merkle4).  Scaling is
 weak: every rank hashes its own 2^20-digest batch, no data-path collective (digests are independent);
-rank 0 broadcasts the constant table over RCCL once, before the timed region.
+rank 0 broadcasts the constant table over RCCL once, before the timed region.  Setup also issues 24 untimed
+launches of the step (`setup.wake_up_launches`) so that an idle GPU's clocks are at steady state whatever W is;
+then W untimed warm-up steps, then exactly K timed steps between barriers + synchronisation, MAX over ranks.
+Other workloads: --workload tree | sponge42 | openings | encrypt (BASELINE configs[2], [3]).
 
 Prints ONE JSON line (rank 0) with `roofline` (VALU int32-MAC bound — DESIGN.md §3; HBM figures are
 included, the path is not HBM- or MFMA-bound) and, at N=1, `cpu_baseline` (the C oracle, kind "port",
