@@ -99,6 +99,12 @@ size_t p252_merkle2_levels_len(size_t n_leaves);
  * failure. */
 void* p252_host_alloc(size_t bytes);
 void p252_host_free(void* p);
+/* Page-lock / release a buffer the caller already owns (hipHostRegister / hipHostUnregister) — e.g. a Rust
+ * Vec<BlsScalar> that is hashed repeatedly: registered once, every later host-buffer call on it runs at the
+ * p252_host_alloc rate instead of paying the per-call page-locking.  The buffer must stay allocated until it is
+ * unregistered.  0 or P252_ERR_HIP / P252_ERR_INVALID_ARGUMENT. */
+int p252_host_register(void* p, size_t bytes);
+int p252_host_unregister(void* p);
 
 /* ---- batched compute, DEVICE buffers (asynchronous on `hip_stream`, a hipStream_t; NULL = the
  * default stream).  Pointers are device addresses with the same layouts as above.  This is the

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "p252_permute_batch", "p252_hash_batch", "p252_merkle4_tree", "p252_merkle4_levels_len",
     "p252_permute_batch_device", "p252_hash_batch_device", "p252_merkle4_tree_device", "p252_sync",
     "p252_truncate250_device", "p252_merkle4_path_batch", "p252_merkle4_path_batch_device",
-    "p252_host_alloc", "p252_host_free", "p252_merkle2_tree", "p252_merkle2_levels_len", "p252_merkle2_tree_device",
+    "p252_host_alloc", "p252_host_free", "p252_host_register", "p252_host_unregister", "p252_merkle2_tree", "p252_merkle2_levels_len", "p252_merkle2_tree_device",
     "p252_encryption_tag", "p252_encrypt_batch", "p252_decrypt_batch", "p252_encrypt_batch_device",
     "p252_decrypt_batch_device",
     "p252_tables_size", "p252_tables_export", "p252_tables_import",
@@ -79,6 +79,8 @@ def lib():
     L.p252_host_alloc.restype = _vp
     L.p252_host_free.argtypes = [_vp]
     L.p252_host_free.restype = None
+    L.p252_host_register.argtypes = [_vp, _sz]
+    L.p252_host_unregister.argtypes = [_vp]
     L.p252_truncate250_device.argtypes = [_vp, _vp, _vp, _sz, _vp]
     _u8p = ctypes.POINTER(ctypes.c_uint8)
     L.p252_merkle4_path_batch.argtypes = [_vp, _u64p, _u64p, _u64p, _u8p, _sz, _u64p, _sz]

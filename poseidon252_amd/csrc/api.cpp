@@ -381,6 +381,24 @@ void p252_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
+int p252_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return P252_ERR_INVALID_ARGUMENT;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return P252_ERR_HIP;
+    }
+    return P252_OK;
+}
+
+int p252_host_unregister(void* p) {
+    if (!p) return P252_ERR_INVALID_ARGUMENT;
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return P252_ERR_HIP;
+    }
+    return P252_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // SURVEY §8(f) "next" rows: truncated outputs and batched Merkle openings
 // ------------------------------------------------------------------------------------------

@@ -288,6 +288,25 @@ class PinnedScalars:
             pass
 
 
+class registered:
+    """`with registered(array):` page-locks a numpy array the caller owns for the duration of the block
+    (p252_host_register / p252_host_unregister): host-buffer calls on it then copy at PCIe speed."""
+
+    def __init__(self, array):
+        self._a = array
+        assert array.flags["C_CONTIGUOUS"]
+
+    def __enter__(self):
+        rc = _lib.lib().p252_host_register(self._a.ctypes.data, self._a.nbytes)
+        if rc:
+            _raise(rc)
+        return self._a
+
+    def __exit__(self, *exc):
+        _lib.lib().p252_host_unregister(self._a.ctypes.data)
+        return False
+
+
 def truncate250(scalars):
     """finalize_truncated's post-processing (hash.rs:164-183): raw limbs for JubJubScalar::from_raw."""
     s = _as_scalars(scalars)
@@ -373,7 +392,7 @@ class HashBatch:
                 out = torch.empty((n, self.out_len, 4), dtype=torch.int64, device=scalars.device)
             self.ctx.hash_batch_device(self.tag, scalars, self.item_len, self.out_len, out, n)
             return out
-        return self.ctx.hash_batch(self.tag, scalars, self.item_len, self.out_len)
+        return self.ctx.hash_batch(self.tag, scalars, self.item_len, self.out_len, out=out)
 
     def digest_truncated(self, scalars):
         """Hash::digest_truncated (hash.rs:203-210) per item; device tensors are truncated on the device"""

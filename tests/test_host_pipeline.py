@@ -33,3 +33,28 @@ def test_pipelined_sponge_multi_output(gpu_ctx, oracle_mod):
     out = hb.digest(m)
     idx = np.arange(0, n, 131)
     assert np.array_equal(out[idx], oracle_mod.hash_batch(hb.tag, m[idx], 42, 5))
+
+
+def test_caller_registered_buffers(gpu_ctx, oracle_mod):
+    """p252_host_register / p252_host_unregister: a caller-owned (numpy) buffer page-locked once is treated like
+    p252_host_alloc memory by the host-buffer entry points; results unchanged, no per-call page-locking"""
+    import time
+    import poseidon252_amd as P
+    from poseidon252_amd import _lib
+    from poseidon252_amd.hash import registered
+    hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=gpu_ctx)
+    n = (1 << 19) + 5
+    x = oracle_mod.fill_random(0x7e9, 4 * n).reshape(n, 4, 4)
+    ref = hb.digest(x)
+    out = np.empty((n, 1, 4), dtype=np.uint64)
+    with registered(x), registered(out):
+        hb.digest(x, out=out)  # warm
+        t0 = time.perf_counter()
+        got = hb.digest(x, out=out)
+        t_reg = time.perf_counter() - t0
+    assert np.array_equal(got.reshape(ref.shape), ref)
+    t0 = time.perf_counter()
+    hb.digest(x, out=out)
+    t_unreg = time.perf_counter() - t0
+    assert t_reg < t_unreg  # no per-call page-locking while registered
+    assert _lib.lib().p252_host_register(None, 16) != 0 and _lib.lib().p252_host_unregister(None) != 0  # argument checks
