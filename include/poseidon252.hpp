@@ -88,6 +88,21 @@ class Context {
     std::shared_ptr<p252_ctx> ctx_;
 };
 
+// Page-locks a caller-owned buffer for its lifetime (p252_host_register / p252_host_unregister): host-buffer calls on it
+// copy at PCIe speed instead of page-locking it on every call.  The buffer must outlive this object.
+class HostRegistration {
+  public:
+    HostRegistration(void* p, std::size_t bytes) : p_(p) {
+        if (p252_host_register(p, bytes) != P252_OK) throw DeviceError("p252_host_register failed");
+    }
+    ~HostRegistration() { (void)p252_host_unregister(p_); }
+    HostRegistration(const HostRegistration&) = delete;
+    HostRegistration& operator=(const HostRegistration&) = delete;
+
+  private:
+    void* p_;
+};
+
 // io_pattern() of src/hash.rs:62-85 plus dusk-safe's validation; throws like Hash::finalize panics
 inline void check_io_pattern(Domain d, const std::vector<std::size_t>& absorb_lens, std::size_t output_len) {
     detail::check(p252_check_io_pattern(static_cast<int>(d), absorb_lens.data(), absorb_lens.size(), output_len), nullptr,

@@ -149,6 +149,10 @@ int main() {
         BlsScalar exp_root;
         p252o_merkle4_tree(hb.tag().data(), leaves[0].data(), leaves.size(), exp_root.data(), nullptr);
         EXPECT(merkle4_root(leaves) == exp_root);
+        {  // caller-owned buffer page-locked for the scope: same digests
+            HostRegistration reg(input.data(), input.size() * sizeof(BlsScalar));
+            EXPECT(hb.digest(input) == got);
+        }
     }
     std::printf(failures ? "C++ HOST API: %d FAILURES\n" : "C++ HOST API: ALL PASSED\n", failures);
     return failures ? 1 : 0;
