@@ -41,6 +41,9 @@ extern "C" {
     pub fn p252_sync(ctx: *mut P252Ctx, stream: *mut c_void) -> c_int;
     pub fn p252_host_alloc(bytes: usize) -> *mut c_void;
     pub fn p252_host_free(p: *mut c_void);
+    /// page-lock / release a caller-owned buffer (e.g. a `Vec<BlsScalar>` hashed repeatedly)
+    pub fn p252_host_register(p: *mut c_void, bytes: usize) -> c_int;
+    pub fn p252_host_unregister(p: *mut c_void) -> c_int;
 }
 
 /// The sponge tag exactly as `Hash::finalize` obtains it (src/hash.rs:131-137): start a sponge with the
