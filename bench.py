@@ -194,12 +194,43 @@ def cpu_baseline(tag, gpu_sample=None):
                     "the Rust reference cannot be built here (no cargo; un-vendored crates)"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: re-execute this command line under
+    torch.distributed.run with N ranks on this node (exactly how the driver launches the N > 1 runs) and
+    hand its output and exit status through.  --gpus is therefore never silently ignored."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required for RCCL across processes on this driver
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d — launch as `python -m torch.distributed.run --nproc-per-node %d ... "
+              "bench.py --gpus %d` (or plain `python bench.py --gpus %d`, which does that itself)"
+              % (args.gpus, world, args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the product has no CPU path", file=sys.stderr)
         sys.exit(2)
@@ -209,6 +240,9 @@ def main():
     backend = os.environ.get("P252_BENCH_BACKEND", "nccl")
     if share_gpu:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        print("bench.py: --gpus %d but only %d HIP device(s) visible" % (world, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -265,11 +299,13 @@ def main():
         from poseidon252_amd import encryption as E
         tag = E.encryption_tag(2)
 
-    # synthetic input generated ON the device (splitmix64-like hash of the index, top bits cleared so
-    # every scalar is < 2^254 < p: a valid Montgomery residue; the permutation cost is data-independent)
+    # synthetic input generated ON the device by SURVEY §8(d)'s generator (splitmix64 stream, rejection-sampled below p:
+    # uniform field elements; poseidon252_amd/synth.py, byte-identical to the oracle's fill_random).  Rank 0's
+    # configs[1] batch (seed 0xc10d) is exactly the one tests/test_gpu_fullsize.py verifies digest by digest.
+    from poseidon252_amd import synth
     g = torch.Generator(device=dev)
     g.manual_seed(0xC10D + rank)
-    d_in = torch.randint(0, 2 ** 62, (in_scalars, 4), dtype=torch.int64, device=dev, generator=g)
+    d_in = synth.splitmix_scalars(0xC10D + rank, in_scalars, dev)
     if wl == "merkle4_digests":
         d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
         step = lambda: ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
@@ -290,6 +326,8 @@ def main():
                 ctx.merkle4_tree_device(tag, roots_dev.contiguous(), world, d_top, None)
             perms_per_step += P.levels_len(world)
             name += " + all-gather of %d subtree roots and top levels" % world
+            if world == 8 and log2n == 24:
+                name += " = 2^27-leaf tree sharded across 8 GPUs (BASELINE configs[4])"
         step()  # allocate the context-owned level scratch outside the timed region
     elif wl == "encrypt":
         d_out = torch.empty((n, 3, 4), dtype=torch.int64, device=dev)
@@ -390,6 +428,9 @@ def main():
             "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "dtype_note": "255-bit field elements as 9 x 29-bit limbs (int32), products accumulated in signed 64-bit columns (v_mad_i64_i32)",
             "config": {"workload": name, "units_per_gpu_per_step": perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
+                       "ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                       "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "input": "splitmix64 seed 0xc10d + rank, uniform mod p (SURVEY §8d)",
                        "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
             "roofline": {
                 "bound": "valu-int32-mac", "kernel": {"sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}.get(wl, "k_merkle4"),

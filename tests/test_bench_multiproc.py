@@ -105,3 +105,30 @@ def test_bench_two_ranks_share_gpu_gloo(gpu_ctx):
     assert "identical to local derivation: True" in d["config"]["constants"]
     # whole-job value = 2 ranks x units / max-over-ranks time
     assert d["value"] == pytest.approx(2 * d["config"]["units_per_gpu_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself(gpu_ctx):
+    """`python bench.py --gpus 2` with NO launcher: bench.py re-executes itself under torch.distributed.run, so
+    --gpus can never be silently ignored.  2 ranks share the one GPU here (test-only switches)."""
+    env = dict(os.environ, P252_BENCH_SHARE_GPU="1", P252_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                   "--log2n", "14"], cwd=ROOT, env=env, timeout=900, stderr=subprocess.DEVNULL)
+    d = _one_json_line(out)
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["collective_backend"] == "gloo"
+    assert d["self_consistency_ok"] is True
+
+
+def test_bench_refuses_more_ranks_than_devices(gpu_ctx):
+    """one rank per GPU: asking for 2 GPUs on a 1-GPU box is an error, not a 1-GPU number"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with a single GPU")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "P252_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log2n", "12",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, timeout=600, capture_output=True)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
