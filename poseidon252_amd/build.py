@@ -56,7 +56,8 @@ def build_hosttest(force=False):
     _gen_assets()
     deps = [os.path.join(CSRC, f) for f in ["hosttest.cpp"] + HEADERS]
     if force or _stale(HOSTTEST_LIB, deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+        # -DP252_TRACK_BOUNDS: the reductions record the largest column / top digit they meet (test_dynamic_bounds)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DP252_TRACK_BOUNDS",
                                os.path.join(CSRC, "hosttest.cpp"), "-o", HOSTTEST_LIB])
     return HOSTTEST_LIB
 

@@ -54,6 +54,39 @@ struct E29 {
     int32_t d[NL];
 };
 
+// Instrumented host build only (tests/test_host_arith.py::test_dynamic_bounds): largest |column| any reduction saw and
+// largest |top digit| any reduction produced.  Compiles to nothing everywhere else.
+#if defined(P252_TRACK_BOUNDS) && !defined(__HIPCC__)
+struct BoundTrack {
+    int64_t max_col = 0;
+    int32_t max_top = 0;   // reduction outputs (multiplicands of generic products)
+    int32_t max_top1 = 0;  // W_0 = 28 X_4 + const (multiplicand of one-digit products only)
+};
+inline BoundTrack& bound_track() {
+    static BoundTrack b;
+    return b;
+}
+inline void trk_col(int64_t v) {
+    if (v < 0) v = -(v + 1);
+    if (v > bound_track().max_col) bound_track().max_col = v;
+}
+inline void trk_top(int32_t d) {
+    if (d < 0) d = -(d + 1);
+    if (d > bound_track().max_top) bound_track().max_top = d;
+}
+#define P252_TRK_COL(v) trk_col(v)
+#define P252_TRK_TOP(d) trk_top(d)
+#define P252_TRK_TOP1(d)                                                        \
+    {                                                                           \
+        int32_t a_ = (d) < 0 ? -((d) + 1) : (d);                                \
+        if (a_ > bound_track().max_top1) bound_track().max_top1 = a_;           \
+    }
+#else
+#define P252_TRK_TOP1(d)
+#define P252_TRK_COL(v)
+#define P252_TRK_TOP(d)
+#endif
+
 // Hides the value range of a freshly masked digit from the optimiser.  Without it LLVM knows the
 // digit is non-negative, treats (int64)digit * (int64)signed_constant as zext x sext and lowers it to
 // TWO v_mad_u64_u32 plus two v_mov (unsigned product + sign correction) instead of ONE
@@ -131,6 +164,7 @@ P252_HD void acc_sqr(A29& t, const E29& a) {
 P252_HD E29 redc(A29& t) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+        P252_TRK_COL(t.c[i]);
         const int64_t lo = opaque_digit((int32_t)((uint32_t)t.c[i] & DMASK));
         t.c[i + 1] += (t.c[i] >> WB) - lo * (int64_t)P252_P29_1;
         t.c[i + 2] -= lo * (int64_t)P252_P29_2;
@@ -146,10 +180,114 @@ P252_HD E29 redc(A29& t) {
 #pragma unroll
     for (int k = 0; k < NL - 1; ++k) {
         const int64_t v = t.c[NL + k] + carry;
+        P252_TRK_COL(t.c[NL + k]);
         r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
+    P252_TRK_COL(t.c[2 * NL - 1] + carry);
     r.d[NL - 1] = opaque_digit((int32_t)(t.c[2 * NL - 1] + carry));
+    P252_TRK_TOP(r.d[NL - 1]);
+    return r;
+}
+
+// ---- the wide Montgomery step (kernels' schedule) ----
+// p = 1 - 2^32 + ... : p == 1 (mod 2^32), not only (mod 2^29).  Take the quotient digit from ALL 32 bits of the column's
+// low register instead of its low 29: q == column (mod 2^32), q in [-2^31, 2^31).  Then column - q is an exact multiple
+// of 2^32, so the carry into the next column, (column - q) / 2^29, is 8 x (the column's HIGH REGISTER): one
+// v_mad_i64_i32 with the constant 8 does sign extension, shift and add, where the 29-bit step needs v_and + v_ashrrev_i64
+// + v_lshl_add_u64 (2 + 4 + 4 cycles).  To read q as a signed number without a correction term the columns that get a
+// step carry a bias of 2^31 (set when the accumulator is initialised — the first multiply-add of a column takes it
+// as its addend, a register pair that lives for the whole kernel): u = low register of (column + 2^31);
+// q = u XOR 2^31 = u - 2^31; (column - q) / 2^32 = high register, exactly.  Cost per step: 1 v_xor + 9 v_mad_i64_i32.
+// Multiples of p are subtracted in BALANCED digits (|p'_k| < 2^28, sum |p'_k| = 2^29.37 where the plain digits sum to
+// 2^31.36), so a column collects less than 2^31 x 2^29.37 = 2^60.4 from a whole reduction although q has 32 bits.
+// Result: V' = (T - m p) / 2^(29 n) with |m| < 2^(29 n + 2)  =>  V' in (T/2^(29 n) - 4.01 p, T/2^(29 n) + 4.01 p): the lazy
+// range inside a permutation is |V| < 7p (top digit < 2^26) instead of < 2p; only the LAST reduction before to_mont4()
+// must be the tight one (redc).
+#define P252_PB_1 (-8) /* = -RK::eight: the step multiplies by the register constant */
+#define P252_PB_2 (-6881344)
+#define P252_PB_3 (-79165952)
+#define P252_PB_4 (-41921220)
+#define P252_PB_5 (201589969)
+#define P252_PB_6 (-182399769)
+#define P252_PB_7 (174404528)
+#define P252_PB_8 (7597479)
+
+// reduction constants that live in registers for a whole kernel (made once, passed down by reference)
+struct RK {
+    int64_t bias;   // 2^31, a VGPR pair: the addend of the first multiply-add of every column that gets a wide step
+    int32_t eight;  // 8, an SGPR the optimiser cannot see through (so that x8 stays a multiply-add, not shift + add)
+    int32_t eight_p1;  // -p'_1 = 8 again, a second opaque copy: with one, h*8 + q*8 is refactored into a 64-bit (h+q)*8
+};
+P252_HD RK make_rk() {
+    RK k;
+    k.bias = (int64_t)1 << 31;
+    k.eight = 8;
+    k.eight_p1 = 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(k.bias));
+    asm("; carry x8" : "+s"(k.eight));  // (distinct strings: identical asm statements would be merged)
+    asm("; -p'_1" : "+s"(k.eight_p1));
+#endif
+    return k;
+}
+
+// one wide step on a column array: c[i] carries the bias; c[i+1] .. c[i+8] (as far as NCOL goes) receive -q p'_k
+#define P252_WSTEP(c, i, NCOL, K)                                                         \
+    {                                                                                     \
+        P252_TRK_COL((c)[i]);                                                             \
+        const int64_t q = opaque_digit((int32_t)((uint32_t)(c)[i] ^ 0x80000000u));        \
+        const int64_t h = (int32_t)((c)[i] >> 32);                                        \
+        (c)[(i) + 1] += h * (int64_t)(K).eight + q * (int64_t)(K).eight_p1; /* p'_1 = -8 */ \
+        if ((i) + 2 < (NCOL)) (c)[(i) + 2] -= q * (int64_t)P252_PB_2;                     \
+        if ((i) + 3 < (NCOL)) (c)[(i) + 3] -= q * (int64_t)P252_PB_3;                     \
+        if ((i) + 4 < (NCOL)) (c)[(i) + 4] -= q * (int64_t)P252_PB_4;                     \
+        if ((i) + 5 < (NCOL)) (c)[(i) + 5] -= q * (int64_t)P252_PB_5;                     \
+        if ((i) + 6 < (NCOL)) (c)[(i) + 6] -= q * (int64_t)P252_PB_6;                     \
+        if ((i) + 7 < (NCOL)) (c)[(i) + 7] -= q * (int64_t)P252_PB_7;                     \
+        if ((i) + 8 < (NCOL)) (c)[(i) + 8] -= q * (int64_t)P252_PB_8;                     \
+    }
+
+// accumulator for a product that will be reduced by redc_w: bias in the nine low columns
+P252_HD void acc_zero_w(A29& t, const RK& K) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        t.c[k] = K.bias;
+        t.c[NL + k] = 0;
+    }
+}
+template <class CP>
+P252_HD void acc_set_hi_c_w(A29& t, CP c, const RK& K) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        t.c[k] = K.bias;
+        t.c[NL + k] = c[k];
+    }
+}
+
+// nine wide steps + the carry chain over the high columns (digits 0..7 in [0, 2^29), top digit signed, |top| < 2^26)
+P252_HD E29 redc_w(A29& t, const RK& K) {
+    P252_WSTEP(t.c, 0, 2 * NL, K)
+    P252_WSTEP(t.c, 1, 2 * NL, K)
+    P252_WSTEP(t.c, 2, 2 * NL, K)
+    P252_WSTEP(t.c, 3, 2 * NL, K)
+    P252_WSTEP(t.c, 4, 2 * NL, K)
+    P252_WSTEP(t.c, 5, 2 * NL, K)
+    P252_WSTEP(t.c, 6, 2 * NL, K)
+    P252_WSTEP(t.c, 7, 2 * NL, K)
+    P252_WSTEP(t.c, 8, 2 * NL, K)
+    E29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = t.c[NL + k] + carry;
+        P252_TRK_COL(t.c[NL + k]);
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
+        carry = v >> WB;
+    }
+    P252_TRK_COL(t.c[2 * NL - 1] + carry);
+    r.d[NL - 1] = opaque_digit((int32_t)(t.c[2 * NL - 1] + carry));
+    P252_TRK_TOP(r.d[NL - 1]);
     return r;
 }
 
@@ -236,6 +374,15 @@ P252_HD E29 mul_c(const E29& x, CP n) {
     return redc(t);
 }
 
+// the same with the wide reduction (result within +-4.01 p of x n / R')
+template <class CP>
+P252_HD E29 mul_c_w(const E29& x, CP n, const RK& K) {
+    A29 t;
+    acc_zero_w(t, K);
+    acc_mul(t, x, n);
+    return redc_w(t, K);
+}
+
 // carry-normalise an element whose digits have drifted (after digit-wise additions)
 P252_HD void normalize(E29& x) {
     int32_t carry = 0;
@@ -285,6 +432,20 @@ P252_HD E29 sbox(const E29& x) {
     acc_zero(t);
     acc_mul(t, x4, x.d);
     return redc(t);
+}
+
+// x^5 with wide reductions: |result| < 0.0142 (|x|/p)^2 ... all three stay below 4.4 p for |x| < 7p
+P252_HD E29 sbox_w(const E29& x, const RK& K) {
+    A29 t;
+    acc_zero_w(t, K);
+    acc_sqr(t, x);
+    const E29 x2 = redc_w(t, K);
+    acc_zero_w(t, K);
+    acc_sqr(t, x2);
+    const E29 x4 = redc_w(t, K);
+    acc_zero_w(t, K);
+    acc_mul(t, x4, x.d);
+    return redc_w(t, K);
 }
 
 // ---- conversion from / to the reference's memory format (4 x u64 Montgomery limbs, R = 2^256) ----

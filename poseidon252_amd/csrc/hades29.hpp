@@ -148,12 +148,12 @@ P252_HD void hades_permute_int(E29 s[WIDTH], TP tab) {
 // ab = A_1..A_4, B_0..B_4 (ints); kg = K_{q+1}[9], G_q[9].  U_{q+1} overwrites U_{q-4}, W_q overwrites W_{q-5}.
 constexpr int HIST = 5;
 template <int QM /* q mod HIST */, class TP>
-P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg) {
+P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, const RK& K) {
     constexpr int Q = QM + HIST;  // keeps (Q - j) % HIST non-negative
-    Ws[Q % HIST] = mul_c(sbox(Us[Q % HIST]), kg + NL);
+    Ws[Q % HIST] = mul_c_w(sbox_w(Us[Q % HIST], K), kg + NL, K);
     int64_t c[NL + 5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) c[k] = 0;
+    for (int k = 0; k < 5; ++k) c[k] = K.bias;  // the five columns that get a (wide) digit step, fr29.hpp
 #pragma unroll
     for (int k = 0; k < NL; ++k) c[5 + k] = kg[k];
 #pragma unroll
@@ -168,18 +168,11 @@ P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg) {
 #pragma unroll
         for (int k = 0; k < NL; ++k) c[k] += (int64_t)Ws[(Q - 4) % HIST].d[k] * b4;
     }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int64_t lo = opaque_digit((int32_t)((uint32_t)c[i] & DMASK));
-        c[i + 1] += (c[i] >> WB) - lo * (int64_t)P252_P29_1;
-        c[i + 2] -= lo * (int64_t)P252_P29_2;
-        c[i + 3] -= lo * (int64_t)P252_P29_3;
-        c[i + 4] -= lo * (int64_t)P252_P29_4;
-        c[i + 5] -= lo * (int64_t)P252_P29_5;
-        c[i + 6] -= lo * (int64_t)P252_P29_6;
-        c[i + 7] -= lo * (int64_t)P252_P29_7;
-        c[i + 8] -= lo * (int64_t)P252_P29_8;
-    }
+    P252_WSTEP(c, 0, NL + 5, K)
+    P252_WSTEP(c, 1, NL + 5, K)
+    P252_WSTEP(c, 2, NL + 5, K)
+    P252_WSTEP(c, 3, NL + 5, K)
+    P252_WSTEP(c, 4, NL + 5, K)
     E29 r;
     int64_t carry = 0;
 #pragma unroll
@@ -188,7 +181,9 @@ P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg) {
         r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
+    P252_TRK_COL(c[NL + 4] + carry);
     r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 4] + carry));
+    P252_TRK_TOP(r.d[NL - 1]);
     Us[(Q + 1) % HIST] = r;
 }
 
@@ -198,10 +193,10 @@ P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg) {
 // then ONE generic product by fix_i = 2^58 R' / den_i; add_i rides in the high columns.
 // n = 8 x (lo, hi) digits: U_58..U_61 then W_57..W_60.
 template <class TP>
-P252_HD E29 exit_row(const E29* const u[4], const E29* const w[4], TP n, TP fix, TP add) {
+P252_HD E29 exit_row(const E29* const u[4], const E29* const w[4], TP n, TP fix, TP add, const RK& K) {
     int64_t c[NL + 6];
 #pragma unroll
-    for (int k = 0; k < NL + 6; ++k) c[k] = 0;
+    for (int k = 0; k < NL + 6; ++k) c[k] = k < 6 ? K.bias : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t ylo = n[2 * r], yhi = n[2 * r + 1], vlo = n[8 + 2 * r], vhi = n[8 + 2 * r + 1];
@@ -213,18 +208,12 @@ P252_HD E29 exit_row(const E29* const u[4], const E29* const w[4], TP n, TP fix,
             c[r + 1 + k] += (int64_t)w[r]->d[k] * vhi;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int64_t lo = opaque_digit((int32_t)((uint32_t)c[i] & DMASK));
-        c[i + 1] += (c[i] >> WB) - lo * (int64_t)P252_P29_1;
-        c[i + 2] -= lo * (int64_t)P252_P29_2;
-        c[i + 3] -= lo * (int64_t)P252_P29_3;
-        c[i + 4] -= lo * (int64_t)P252_P29_4;
-        c[i + 5] -= lo * (int64_t)P252_P29_5;
-        c[i + 6] -= lo * (int64_t)P252_P29_6;
-        c[i + 7] -= lo * (int64_t)P252_P29_7;
-        c[i + 8] -= lo * (int64_t)P252_P29_8;
-    }
+    P252_WSTEP(c, 0, NL + 6, K)
+    P252_WSTEP(c, 1, NL + 6, K)
+    P252_WSTEP(c, 2, NL + 6, K)
+    P252_WSTEP(c, 3, NL + 6, K)
+    P252_WSTEP(c, 4, NL + 6, K)
+    P252_WSTEP(c, 5, NL + 6, K)
     E29 r;
     int64_t carry = 0;
 #pragma unroll
@@ -233,21 +222,23 @@ P252_HD E29 exit_row(const E29* const u[4], const E29* const w[4], TP n, TP fix,
         r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
+    P252_TRK_COL(c[NL + 5] + carry);
     r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 5] + carry));
+    P252_TRK_TOP(r.d[NL - 1]);
     A29 t;
-    acc_set_hi_c(t, add);
+    acc_set_hi_c_w(t, add, K);
     acc_mul(t, r, fix);
-    return redc(t);
+    return redc_w(t, K);
 }
 
 // Entry row i (virtual history U_0, U_-1, U_-2): an integer combination of the S-box outputs 0..3 of full round 3
 // (NDIG-digit coefficients, NDIG Montgomery digit steps), then ONE generic product by fix_i; add_i rides in the
 // high columns.  n = 4 x (lo, hi) digits.
 template <int NDIG, class TP>
-P252_HD E29 entry_row(const E29 x[WIDTH], TP n, TP fix, TP add) {
+P252_HD E29 entry_row(const E29 x[WIDTH], TP n, TP fix, TP add, const RK& K) {
     int64_t c[NL + NDIG];
 #pragma unroll
-    for (int k = 0; k < NL + NDIG; ++k) c[k] = 0;
+    for (int k = 0; k < NL + NDIG; ++k) c[k] = k < NDIG ? K.bias : 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t lo = n[2 * j], hi = n[2 * j + 1];
@@ -257,18 +248,8 @@ P252_HD E29 entry_row(const E29 x[WIDTH], TP n, TP fix, TP add) {
             if (NDIG == 2) c[k + 1] += (int64_t)x[j].d[k] * hi;
         }
     }
-#pragma unroll
-    for (int i = 0; i < NDIG; ++i) {
-        const int64_t lo = opaque_digit((int32_t)((uint32_t)c[i] & DMASK));
-        c[i + 1] += (c[i] >> WB) - lo * (int64_t)P252_P29_1;
-        if (i + 2 < NL + NDIG) c[i + 2] -= lo * (int64_t)P252_P29_2;
-        if (i + 3 < NL + NDIG) c[i + 3] -= lo * (int64_t)P252_P29_3;
-        if (i + 4 < NL + NDIG) c[i + 4] -= lo * (int64_t)P252_P29_4;
-        if (i + 5 < NL + NDIG) c[i + 5] -= lo * (int64_t)P252_P29_5;
-        if (i + 6 < NL + NDIG) c[i + 6] -= lo * (int64_t)P252_P29_6;
-        if (i + 7 < NL + NDIG) c[i + 7] -= lo * (int64_t)P252_P29_7;
-        if (i + 8 < NL + NDIG) c[i + 8] -= lo * (int64_t)P252_P29_8;
-    }
+    P252_WSTEP(c, 0, NL + NDIG, K)
+    if (NDIG == 2) P252_WSTEP(c, 1, NL + NDIG, K)
     E29 r;
     int64_t carry = 0;
 #pragma unroll
@@ -277,11 +258,13 @@ P252_HD E29 entry_row(const E29 x[WIDTH], TP n, TP fix, TP add) {
         r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
+    P252_TRK_COL(c[NL + NDIG - 1] + carry);
     r.d[NL - 1] = opaque_digit((int32_t)(c[NL + NDIG - 1] + carry));
+    P252_TRK_TOP(r.d[NL - 1]);
     A29 t;
-    acc_set_hi_c(t, add);
+    acc_set_hi_c_w(t, add, K);
     acc_mul(t, r, fix);
-    return redc(t);
+    return redc_w(t, K);
 }
 
 // x * m + add for a small integer m (W_0 = 28 X_4 + const): nine products and a carry chain, no reduction —
@@ -297,7 +280,9 @@ P252_HD E29 small_mul_add(const E29& x, int32_t m, TP add) {
         r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
+    P252_TRK_COL((int64_t)x.d[NL - 1] * mm + (int64_t)add[NL - 1] + carry);
     r.d[NL - 1] = opaque_digit((int32_t)((int64_t)x.d[NL - 1] * mm + (int64_t)add[NL - 1] + carry));
+    P252_TRK_TOP1(r.d[NL - 1]);
     return r;
 }
 
@@ -311,6 +296,7 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
     static_assert(PARTIAL_ROUNDS % HIST == 0, "60 ARMA rounds must split evenly");
+    const RK K = make_rk();  // bias 2^31 / constant 8 of the wide Montgomery step (fr29.hpp), in registers throughout
 #pragma unroll
     for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
 #pragma unroll 1
@@ -320,7 +306,7 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
             const TP kap = tab + Lay::AI_KAPPA + f * WIDTH * NL;
             E29 x[WIDTH];
 #pragma unroll
-            for (int j = 0; j < WIDTH; ++j) x[j] = sbox(s[j]);
+            for (int j = 0; j < WIDTH; ++j) x[j] = sbox_w(s[j], K);
             if (f == RF - 1) {  // the linear layer of round 3 is the entry below: hand over the S-box outputs
 #pragma unroll
                 for (int i = 0; i < WIDTH; ++i) s[i] = x[i];
@@ -335,11 +321,11 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
             Us[1] = int_row(s, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + ((RF - 1) * WIDTH + 4) * NL);  // U_1
             sched_fence();
             // U_0, U_-1, U_-2: virtual
-            Us[0] = entry_row<1>(s, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD);
+            Us[0] = entry_row<1>(s, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD, K);
             sched_fence();
-            Us[HIST - 1] = entry_row<1>(s, tab + Lay::AI_ENT_N + NL, tab + Lay::AI_ENT_FIX + NL, tab + Lay::AI_ENT_ADD + NL);
+            Us[HIST - 1] = entry_row<1>(s, tab + Lay::AI_ENT_N + NL, tab + Lay::AI_ENT_FIX + NL, tab + Lay::AI_ENT_ADD + NL, K);
             sched_fence();
-            Us[HIST - 2] = entry_row<2>(s, tab + Lay::AI_ENT_N + 2 * NL, tab + Lay::AI_ENT_FIX + 2 * NL, tab + Lay::AI_ENT_ADD + 2 * NL);
+            Us[HIST - 2] = entry_row<2>(s, tab + Lay::AI_ENT_N + 2 * NL, tab + Lay::AI_ENT_FIX + 2 * NL, tab + Lay::AI_ENT_ADD + 2 * NL, K);
             sched_fence();
             Us[2] = e29_zero();  // (free slot)
             // W_0: virtual, = the lane-4 S-box output at the W scale (28 = 13 D / K); W_-1, W_-2, W_-3 = 0
@@ -349,18 +335,18 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
 #pragma unroll 1
             for (int it = 0; it < PARTIAL_ROUNDS / HIST; ++it) {  // rounds q = 5 it + 1 .. 5 it + 5
                 const TP kg = tab + Lay::AI_KG + it * HIST * 2 * NL;
-                ai_round<1>(Us, Ws, tab + Lay::AI_AB, kg);
-                ai_round<2>(Us, Ws, tab + Lay::AI_AB, kg + 2 * NL);
-                ai_round<3>(Us, Ws, tab + Lay::AI_AB, kg + 4 * NL);
-                ai_round<4>(Us, Ws, tab + Lay::AI_AB, kg + 6 * NL);
-                ai_round<0>(Us, Ws, tab + Lay::AI_AB, kg + 8 * NL);
+                ai_round<1>(Us, Ws, tab + Lay::AI_AB, kg, K);
+                ai_round<2>(Us, Ws, tab + Lay::AI_AB, kg + 2 * NL, K);
+                ai_round<3>(Us, Ws, tab + Lay::AI_AB, kg + 4 * NL, K);
+                ai_round<4>(Us, Ws, tab + Lay::AI_AB, kg + 6 * NL, K);
+                ai_round<0>(Us, Ws, tab + Lay::AI_AB, kg + 8 * NL, K);
             }
             // after round 60 (60 mod 5 = 0): U_58..U_61 at Us[3], Us[4], Us[0], Us[1]; W_57..W_60 at Ws[2], Ws[3], Ws[4], Ws[0]
             const E29* const us[4] = {&Us[3], &Us[4], &Us[0], &Us[1]};
             const E29* const ws[4] = {&Ws[2], &Ws[3], &Ws[4], &Ws[0]};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                s[i] = exit_row(us, ws, tab + Lay::AI_EX_N + i * 2 * NL, tab + Lay::AI_EX_FIX + i * NL, tab + Lay::AI_EX_ADD + i * NL);
+                s[i] = exit_row(us, ws, tab + Lay::AI_EX_N + i * 2 * NL, tab + Lay::AI_EX_FIX + i * NL, tab + Lay::AI_EX_ADD + i * NL, K);
                 sched_fence();
             }
             s[4] = Us[1];

@@ -145,4 +145,33 @@ int ht_int_ok(int tweak) {
 }
 
 double ht_max_column_bound29() { return max_column_bound29(tab29().data()); }
+
+// instrumented build (-DP252_TRACK_BOUNDS): largest |column| seen by / |top digit| produced by any reduction since the
+// last reset; -1 when the library was built without the instrumentation
+void ht_bounds_reset() {
+#if defined(P252_TRACK_BOUNDS)
+    bound_track() = BoundTrack();
+#endif
+}
+double ht_bounds_max_col() {
+#if defined(P252_TRACK_BOUNDS)
+    return (double)bound_track().max_col;
+#else
+    return -1.0;
+#endif
+}
+double ht_bounds_max_top1() {
+#if defined(P252_TRACK_BOUNDS)
+    return (double)bound_track().max_top1;
+#else
+    return -1.0;
+#endif
+}
+double ht_bounds_max_top() {
+#if defined(P252_TRACK_BOUNDS)
+    return (double)bound_track().max_top;
+#else
+    return -1.0;
+#endif
+}
 }

@@ -11,10 +11,12 @@
 #include "hades29.hpp"
 #include "kernels.h"
 
-// developer switch for A/B experiments (bench_tools/ab_variants.sh):
-// -DP252_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' (occupancy of k_merkle4)
+// Occupancy target of the single-digest kernels: 3 waves per SIMD (512 / 3 = 170 VGPRs).  Left alone the
+// register allocator lands one register above that (169: two waves); told the target it schedules the same
+// instruction stream into 146 registers with no spills and no extra moves.
+// (A/B experiments, bench_tools/ab_variants.sh: -DP252_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'.)
 #ifndef P252_WAVES_ATTR
-#define P252_WAVES_ATTR
+#define P252_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 
 namespace p252 {
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_truncate250(const Scalar32* __re
 // Per level l the node hashed is Hash::digest(Merkle4, children) with children[pos[l]] = current value
 // and the 3 siblings in the remaining slots in order; depth sequential permutations per lane.
 // Layout: leaves[n], siblings[n][depth][3], positions[n][depth] (u8, 0..3), roots[n]. ----
-__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path(const int32_t* __restrict__ tab, TagArg tag,
+__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path(const int32_t* __restrict__ tab, TagArg tag,
                                                              const Scalar32* __restrict__ leaves,
                                                              const Scalar32* __restrict__ siblings,
                                                              const uint8_t* __restrict__ positions,

@@ -607,15 +607,24 @@ inline std::vector<int32_t> encode_tables29(const HadesTables& T) {
 }
 
 // Worst-case |column| (as a double) over every lazy accumulation the three schedules perform, for the
-// ACTUAL constants in `tab`: state digits are bounded by 2^29 (un-carried lanes of schedule (B) by 2^30.1,
-// top digits by 2^25: |V| < 4p), the high-column initialisation by 2^30, and a full reduction adds at most
-// 2^29 * sum(p digits) + carries.  The kernels are correct iff this stays below 2^63.
+// ACTUAL constants in `tab`: state digits are bounded by 2^29 (un-carried lanes of schedule (B) by 2^30.1),
+// top digits by 2^27 (|V| < 16 p; the values the kernels' schedule produces stay below 13 p — measured by the
+// instrumented host build, tests/test_host_arith.py::test_dynamic_bounds), the high-column initialisation by 2^30.
+// A full tight reduction (redc) adds at most 2^29 * sum(p digits) + carries; a wide one (redc_w, the kernels' schedule
+// (C) and its S-boxes) at most 2^31 * sum |balanced p digits| + 8 * 2^31 of carry + the 2^31 bias — the larger of the
+// two is charged everywhere.  The kernels are correct iff this stays below 2^63.
 inline double max_column_bound29(const int32_t* tab) {
     typedef Tab29Layout Lay;
-    const double DIG = 536870912.0 /* 2^29 */, TOP = 33554432.0 /* 2^25 */, LAZY = 1151000000.0 /* 2^30.1 */;
+    const double DIG = 536870912.0 /* 2^29 */, TOP = 134217728.0 /* 2^27 */, LAZY = 1151000000.0 /* 2^30.1 */;
     const double P_SUM = (double)P252_P29_1 + P252_P29_2 + P252_P29_3 + P252_P29_4 + P252_P29_5 + P252_P29_6 +
                          P252_P29_7 + P252_P29_8;
-    const double REDC = DIG * P_SUM + 68719476736.0 /* carries < 2^36 */ + 1073741824.0 /* hi init 2^30 */;
+    auto ab = [](double v) { return v < 0 ? -v : v; };
+    const double PB_SUM = ab(P252_PB_1) + ab(P252_PB_2) + ab(P252_PB_3) + ab(P252_PB_4) + ab(P252_PB_5) + ab(P252_PB_6) +
+                          ab(P252_PB_7) + ab(P252_PB_8);
+    const double REDC_T = DIG * P_SUM + 68719476736.0 /* carries < 2^36 */ + 1073741824.0 /* hi init 2^30 */;
+    const double REDC_W = 2147483648.0 * PB_SUM + 8.0 * 2147483648.0 + 2147483648.0 + 1073741824.0;
+    const double REDC = REDC_T > REDC_W ? REDC_T : REDC_W;
+    const double WSTEP = 2147483648.0 * ab(P252_PB_5);  // the largest single contribution of one wide step to a column
     double worst = 0;
     auto absd = [](int32_t v) { return v < 0 ? -(double)v : (double)v; };
     auto group = [&](std::initializer_list<int> offsets) {  // sum of 9-digit x 9-digit products into 18 columns
@@ -648,14 +657,14 @@ inline double max_column_bound29(const int32_t* tab) {
             group({Lay::AI_ENT_FIX + i * NL});
             double esum = 0;  // integer entry row: at most one digit product per coefficient digit per column, two digit steps
             for (int t = 0; t < 8; ++t) esum += absd(tab[Lay::AI_ENT_N + i * NL + t]);
-            const double erow = DIG * esum + 2.0 * DIG * (double)P252_P29_1 + 68719476736.0;
+            const double erow = DIG * esum + 2.0 * WSTEP + 68719476736.0;
             if (erow > worst) worst = erow;
         }
         group({Lay::AI_EX_FIX + i * NL});
         // integer exit row: a column collects at most one digit product per coefficient digit (16 of them), then six digit steps
         double nsum = 0;
         for (int t = 0; t < 16; ++t) nsum += absd(tab[Lay::AI_EX_N + i * 2 * NL + t]);
-        const double row = DIG * nsum + 6.0 * DIG * (double)P252_P29_1 + 68719476736.0;
+        const double row = DIG * nsum + 6.0 * WSTEP + 68719476736.0;
         if (row > worst) worst = row;
     }
     {  // integer rows: five one-digit terms (row 0 has the largest sum) of possibly un-carried lanes + kappa + one digit step
@@ -667,7 +676,7 @@ inline double max_column_bound29(const int32_t* tab) {
     {  // integer ARMA row: a column collects at most one digit of each of the nine terms, then five digit steps
         double asum = 0;
         for (int t = 0; t < NL; ++t) asum += absd(tab[Lay::AI_AB + t]);
-        const double row = DIG * asum + 5.0 * DIG * (double)P252_P29_1 + 268435456.0 + 68719476736.0;
+        const double row = 2.0 * DIG * asum /* W_0 = 28 X_4: top digit up to 2^30 */ + 5.0 * WSTEP + 268435456.0 + 68719476736.0;
         if (row > worst) worst = row;
     }
     // S-box: element x element (9 products of 2^29 x 2^29) and squarings (<= 4.5 * 2^59)

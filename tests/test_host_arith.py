@@ -206,3 +206,29 @@ def test_adversarial_noncanonical_limbs(oracle_mod, hosttest_lib):
             exp = pymodel.perm_reference([v * Rinv % P for v in s], C, M)
             assert [oracle_mod.int_from_mont(x) for x in o] == exp
             assert all(oracle_mod.lib().p252o_is_reduced(p(x)) for x in o)  # outputs are always canonical
+
+
+def test_dynamic_bounds(oracle_mod, hosttest_lib):
+    """Instrumented host build of the kernels' schedule: the largest |column| any reduction meets and the largest
+    |top digit| any reduction produces, over random, edge and adversarial (non-canonical, digit-saturating) states,
+    stay inside what the static analysis (max_column_bound29) assumes: columns < 2^63, top digits < 2^27 (the
+    wide Montgomery step lets values drift to several p; W_0 = 28 X_4 is the largest: below 2^31 as an int32 digit)."""
+    import math
+    for f in (hosttest_lib.ht_bounds_max_col, hosttest_lib.ht_bounds_max_top, hosttest_lib.ht_bounds_max_top1):
+        f.restype = ctypes.c_double
+    hosttest_lib.ht_bounds_reset()
+    if hosttest_lib.ht_bounds_max_col() < 0:
+        pytest.skip("hosttest library built without -DP252_TRACK_BOUNDS")
+    pats = [(1 << 256) - 1, (1 << 255) + 12345, P, P - 1, 0, 1, 2 * P - 1, 4 * P + 3, int("55" * 32, 16), int("aa" * 32, 16),
+            sum(((1 << 29) - 1) << (29 * i) for i in range(8)) | (((1 << 24) - 1) << 232), (1 << 256) - (1 << 200)]
+    rng = random.Random(11)
+    states = [[rng.choice(pats) for _ in range(5)] for _ in range(300)] + [[v] * 5 for v in pats]
+    st = np.array([[oracle_mod.int_to_limbs(v) for v in s] for s in states], dtype=np.uint64)
+    st = np.concatenate([st, oracle_mod.fill_random(77, 5 * 3000).reshape(3000, 5, 4)])
+    out = np.empty_like(st)
+    hosttest_lib.ht_permute29_sched(p(st), p(out), st.shape[0], 0)
+    col, top, top1 = hosttest_lib.ht_bounds_max_col(), hosttest_lib.ht_bounds_max_top(), hosttest_lib.ht_bounds_max_top1()
+    assert 2 ** 58 < col < 2 ** 62.6, math.log2(col)
+    assert top < 2 ** 27, math.log2(top)     # what max_column_bound29 assumes for the multiplicands of generic products
+    assert top1 < 2 ** 30, math.log2(top1)   # W_0 = 28 X_4: enters one-digit products only (charged as 2 x 2^29 there)
+    print("max |column| 2^%.2f, max |top digit| 2^%.2f (W_0: 2^%.2f)" % (math.log2(col), math.log2(top), math.log2(top1)))
