@@ -141,17 +141,30 @@ int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const v
  * BlsScalars (encryption.rs:66-69), nonce = 1 scalar; cipher = len + 1 scalars (masked message + MAC).
  * Layouts: messages[n][len], secrets[n][2], nonces[n], ciphers[n][len+1], ok[n] bytes (1 = MAC verified;
  * 0 = dusk_poseidon::Error::DecryptionFailed, src/error.rs:27-29, and that item's message output is
- * unspecified).  The construction is restated from SAFE with the KAT-pinned sponge mechanics; its
- * byte-level agreement with the un-vendored dusk-safe 0.3 is UNPINNED (the reference tests only round
- * trips).  `tag` as everywhere: pass the real crate's value, or p252_encryption_tag() (UNPINNED). */
-int p252_encryption_tag(size_t message_len, uint64_t tag_out[4]);
-int p252_encrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* messages, const uint64_t* secrets,
+ * unspecified).
+ *
+ * `variant` selects the sponge-call sequence.  dusk-safe 0.3 is not vendored in the reference and the reference's
+ * tests (tests/encryption.rs:30-115, message lengths 42 and 21) are round trips and failures only, so NO reference
+ * value pins the construction; both candidates run on the KAT-pinned sponge state machine, and the library, its
+ * p252_encryption_tag() and the test oracle all derive from one call table per variant:
+ *   P252_CRYPT_STREAM (0, the default of every wrapper — dusk-safe's encrypt as published, to the best of three
+ *       independent recollections): io-pattern [Absorb(2), Absorb(1), Squeeze(len), Absorb(len), Squeeze(1)]:
+ *       absorb secret, absorb nonce, squeeze ALL len masks, absorb the whole message, squeeze the MAC;
+ *       cipher[i] = message[i] + mask[i], cipher[len] = MAC.
+ *   P252_CRYPT_DUPLEX (1, what version 0.2 of this library shipped): [Absorb(2), Absorb(1), {Squeeze(c), Absorb(c)}*,
+ *       Squeeze(1)] with c = min(4, remaining): squeeze / absorb chunk by chunk.
+ * The two are identical for len <= 4 and differ beyond.  bindings/rust/tests/parity.rs decides between them on a
+ * machine with the dusk crates.  `tag` as everywhere: pass the real crate's value, or p252_encryption_tag() (UNPINNED). */
+#define P252_CRYPT_STREAM 0
+#define P252_CRYPT_DUPLEX 1
+int p252_encryption_tag(int variant, size_t message_len, uint64_t tag_out[4]);
+int p252_encrypt_batch(p252_ctx* ctx, int variant, const uint64_t tag[4], const uint64_t* messages, const uint64_t* secrets,
                        const uint64_t* nonces, size_t len, uint64_t* ciphers, size_t n);
-int p252_decrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* ciphers, const uint64_t* secrets,
+int p252_decrypt_batch(p252_ctx* ctx, int variant, const uint64_t tag[4], const uint64_t* ciphers, const uint64_t* secrets,
                        const uint64_t* nonces, size_t len, uint64_t* messages, uint8_t* ok, size_t n);
-int p252_encrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_messages, const void* d_secrets,
+int p252_encrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4], const void* d_messages, const void* d_secrets,
                               const void* d_nonces, size_t len, void* d_ciphers, size_t n, void* hip_stream);
-int p252_decrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
+int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
                               const void* d_nonces, size_t len, void* d_messages, void* d_ok, size_t n, void* hip_stream);
 
 /* ---- constant-table exchange (multi-GPU: rank 0 broadcasts its derived table over RCCL, every

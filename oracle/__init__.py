@@ -175,18 +175,21 @@ def merkle4_path_batch(tag, leaves, siblings, positions):
     return roots
 
 
-def encryption_tag(message_len):
+CRYPT_STREAM, CRYPT_DUPLEX = 0, 1  # p252_oracle.h: the two candidate dusk_safe::encrypt call sequences
+
+
+def encryption_tag(message_len, variant=CRYPT_STREAM):
     """UNPINNED (see p252_oracle.h)"""
     out = np.empty(4, dtype=np.uint64)
-    f = lib().p252o_encryption_tag
-    f.argtypes = [ctypes.c_size_t, _u64p]
+    f = lib().p252o_encryption_tag_v
+    f.argtypes = [ctypes.c_int, ctypes.c_size_t, _u64p]
     f.restype = ctypes.c_int
-    if f(message_len, _p(out)):
-        raise ValueError("invalid message length")
+    if f(variant, message_len, _p(out)):
+        raise ValueError("invalid message length / variant")
     return out
 
 
-def encrypt_batch(tag, messages, secrets, nonces):
+def encrypt_batch(tag, messages, secrets, nonces, variant=CRYPT_STREAM):
     """messages (n,len,4), secrets (n,2,4), nonces (n,4) -> ciphers (n,len+1,4)"""
     tag = _c(tag).reshape(4)
     secrets = _c(secrets).reshape(-1, 2, 4)
@@ -195,16 +198,16 @@ def encrypt_batch(tag, messages, secrets, nonces):
     nonces = _c(nonces).reshape(n, 4)
     ln = messages.shape[1]
     out = np.empty((n, ln + 1, 4), dtype=np.uint64)
-    f = lib().p252o_encrypt
-    f.argtypes = [_u64p, _u64p, ctypes.c_size_t, _u64p, _u64p, _u64p]
+    f = lib().p252o_encrypt_v
+    f.argtypes = [ctypes.c_int, _u64p, _u64p, ctypes.c_size_t, _u64p, _u64p, _u64p]
     f.restype = ctypes.c_int
     for i in range(n):
-        if f(_p(tag), _p(messages[i]), ln, _p(secrets[i]), _p(nonces[i]), _p(out[i])):
-            raise ValueError("empty message")
+        if f(variant, _p(tag), _p(messages[i]), ln, _p(secrets[i]), _p(nonces[i]), _p(out[i])):
+            raise ValueError("empty message / bad variant")
     return out
 
 
-def decrypt_batch(tag, ciphers, secrets, nonces):
+def decrypt_batch(tag, ciphers, secrets, nonces, variant=CRYPT_STREAM):
     """ciphers (n,len+1,4) -> (messages (n,len,4), ok (n,) bool)"""
     tag = _c(tag).reshape(4)
     secrets = _c(secrets).reshape(-1, 2, 4)
@@ -214,11 +217,11 @@ def decrypt_batch(tag, ciphers, secrets, nonces):
     ln = ciphers.shape[1] - 1
     out = np.empty((n, ln, 4), dtype=np.uint64)
     ok = np.zeros(n, dtype=bool)
-    f = lib().p252o_decrypt
-    f.argtypes = [_u64p, _u64p, ctypes.c_size_t, _u64p, _u64p, _u64p]
+    f = lib().p252o_decrypt_v
+    f.argtypes = [ctypes.c_int, _u64p, _u64p, ctypes.c_size_t, _u64p, _u64p, _u64p]
     f.restype = ctypes.c_int
     for i in range(n):
-        ok[i] = f(_p(tag), _p(ciphers[i]), ln, _p(secrets[i]), _p(nonces[i]), _p(out[i])) == 0
+        ok[i] = f(variant, _p(tag), _p(ciphers[i]), ln, _p(secrets[i]), _p(nonces[i]), _p(out[i])) == 0
     return out, ok
 
 

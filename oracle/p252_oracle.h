@@ -100,13 +100,23 @@ int p252o_tag(int domain, const size_t *absorb_lens, size_t n_absorbs, size_t ou
 void p252o_blake2b512(const uint8_t *msg, size_t len, uint8_t out[64]);
 
 /* ---- UNPINNED: encryption (src/encryption.rs:62-95 -> dusk_safe::encrypt/decrypt, un-vendored).
- * io-pattern [Absorb(2), Absorb(1), {Squeeze(c), Absorb(c)}*, Squeeze(1)], c = min(4, remaining);
- * cipher = message + squeezed mask, followed by one squeezed element (the MAC).  The secret is the
- * two coordinates of the JubJub shared point (encryption.rs:62-76) as BlsScalars. ---- */
+ * The literal sponge-call sequence, two candidates behind `variant`:
+ *   P252O_CRYPT_STREAM (default): [Absorb(2), Absorb(1), Squeeze(len), Absorb(len), Squeeze(1)]
+ *   P252O_CRYPT_DUPLEX:           [Absorb(2), Absorb(1), {Squeeze(c), Absorb(c)}*, Squeeze(1)], c = min(4, remaining)
+ * cipher[i] = message[i] + mask[i] followed by the last squeezed element (the MAC).  The secret is the two
+ * coordinates of the JubJub shared point (encryption.rs:62-76) as BlsScalars.  The un-suffixed functions are
+ * variant P252O_CRYPT_STREAM. ---- */
+#define P252O_CRYPT_STREAM 0
+#define P252O_CRYPT_DUPLEX 1
+int p252o_encryption_tag_v(int variant, size_t message_len, uint64_t tag_out[4]);
+int p252o_encrypt_v(int variant, const uint64_t tag[4], const uint64_t *message, size_t len, const uint64_t secret[8],
+                    const uint64_t nonce[4], uint64_t *cipher /* len + 1 */);
+/* 0 ok, -1 DecryptionFailed */
+int p252o_decrypt_v(int variant, const uint64_t tag[4], const uint64_t *cipher /* len + 1 */, size_t len,
+                    const uint64_t secret[8], const uint64_t nonce[4], uint64_t *message);
 int p252o_encryption_tag(size_t message_len, uint64_t tag_out[4]);
 int p252o_encrypt(const uint64_t tag[4], const uint64_t *message, size_t len, const uint64_t secret[8],
                   const uint64_t nonce[4], uint64_t *cipher /* len + 1 */);
-/* 0 ok, -1 DecryptionFailed */
 int p252o_decrypt(const uint64_t tag[4], const uint64_t *cipher /* len + 1 */, size_t len, const uint64_t secret[8],
                   const uint64_t nonce[4], uint64_t *message);
 

@@ -70,11 +70,11 @@ def lib():
     L.p252_merkle4_tree_device.argtypes = [_vp, _u64p, _vp, _sz, _vp, _vp, _vp]
     L.p252_sync.argtypes = [_vp, _vp]
     _u8p2 = ctypes.POINTER(ctypes.c_uint8)
-    L.p252_encryption_tag.argtypes = [_sz, _u64p]
-    L.p252_encrypt_batch.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p, _sz, _u64p, _sz]
-    L.p252_decrypt_batch.argtypes = [_vp, _u64p, _u64p, _u64p, _u64p, _sz, _u64p, _u8p2, _sz]
-    L.p252_encrypt_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
-    L.p252_decrypt_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
+    L.p252_encryption_tag.argtypes = [ctypes.c_int, _sz, _u64p]
+    L.p252_encrypt_batch.argtypes = [_vp, ctypes.c_int, _u64p, _u64p, _u64p, _u64p, _sz, _u64p, _sz]
+    L.p252_decrypt_batch.argtypes = [_vp, ctypes.c_int, _u64p, _u64p, _u64p, _u64p, _sz, _u64p, _u8p2, _sz]
+    L.p252_encrypt_batch_device.argtypes = [_vp, ctypes.c_int, _u64p, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
+    L.p252_decrypt_batch_device.argtypes = [_vp, ctypes.c_int, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
     L.p252_host_alloc.argtypes = [_sz]
     L.p252_host_alloc.restype = _vp
     L.p252_host_free.argtypes = [_vp]

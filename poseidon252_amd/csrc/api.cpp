@@ -31,6 +31,12 @@ struct p252_ctx {
     void* d_lvl[2] = {nullptr, nullptr};
     size_t d_lvl_cap[2] = {0, 0};
     hipStream_t streams[3] = {nullptr, nullptr, nullptr};  // host-buffer pipeline (created on first use)
+    // encryption: the sponge-call program of the last (variant, message_len) used, uploaded once (k_crypt interprets it)
+    uint32_t* d_prog = nullptr;
+    size_t d_prog_cap = 0;
+    int prog_variant = -1;
+    size_t prog_len = 0;
+    unsigned prog_calls = 0;
     std::string err;
 };
 
@@ -135,6 +141,7 @@ void p252_destroy(p252_ctx* ctx) {
         if (ctx->d_lvl[i]) (void)hipFree(ctx->d_lvl[i]);
     for (int i = 0; i < 3; ++i)
         if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
+    if (ctx->d_prog) (void)hipFree(ctx->d_prog);
     delete ctx;
 }
 
@@ -452,35 +459,75 @@ int p252_merkle4_path_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t
     return P252_OK;
 }
 
-// ---- encryption row (src/encryption.rs:62-95) ----
-static int crypt_device(p252_ctx* ctx, bool decrypt, const uint64_t tag[4], const void* d_in, const void* d_secrets,
+// ---- encryption row (src/encryption.rs:62-95 -> dusk_safe::encrypt / decrypt) ----
+// The sponge-call sequence dusk_safe::encrypt makes, as a table (one word per call: kind << 29 | len; kinds as in
+// kernels.hip k_crypt).  Two candidates (include/poseidon252_hip.h): P252_CRYPT_STREAM — squeeze all `len` masks, then
+// absorb the whole message — and P252_CRYPT_DUPLEX — squeeze / absorb per chunk of <= 4.  Adding a third is one more
+// branch here: the kernel, the tag and the oracle all derive from the table.
+static std::vector<uint32_t> crypt_program(int variant, size_t len) {
+    std::vector<uint32_t> prog;
+    auto call = [&](uint32_t kind, size_t n) { prog.push_back((kind << 29) | (uint32_t)n); };
+    call(0, 2);  // Absorb(2): shared secret (u, v)
+    call(1, 1);  // Absorb(1): nonce
+    if (variant == P252_CRYPT_STREAM) {
+        call(2, len);  // Squeeze(len): masks
+        call(3, len);  // Absorb(len): message
+    } else {
+        for (size_t left = len; left;) {
+            const size_t c = left < 4 ? left : 4;
+            call(2, c);
+            call(3, c);
+            left -= c;
+        }
+    }
+    call(4, 1);  // Squeeze(1): MAC
+    return prog;
+}
+
+static bool crypt_variant_ok(int variant) { return variant == P252_CRYPT_STREAM || variant == P252_CRYPT_DUPLEX; }
+
+static int crypt_device(p252_ctx* ctx, int variant, bool decrypt, const uint64_t tag[4], const void* d_in, const void* d_secrets,
                         const void* d_nonces, size_t len, void* d_out, void* d_ok, size_t n, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (!crypt_variant_ok(variant)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: unknown variant");
     if (len == 0) return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "encrypt/decrypt: empty message");
-    if (len > 0x7ffffff0u) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: message too long");
+    if (len >= 0x1ffffff0u) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: message too long");
     if (n == 0) return P252_OK;
     if (!tag || !d_in || !d_secrets || !d_nonces || !d_out || (decrypt && !d_ok))
         return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: NULL buffer");
     if (misaligned(d_in) || misaligned(d_secrets) || misaligned(d_nonces) || misaligned(d_out)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_crypt(decrypt, ctx->d_tab, tag_arg(tag), d_in, d_secrets, d_nonces, (unsigned)len, d_out, d_ok, n,
-                              (hipStream_t)hip_stream));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (ctx->prog_variant != variant || ctx->prog_len != len) {
+        const std::vector<uint32_t> prog = crypt_program(variant, len);
+        // the previous program may still be read by a kernel in flight on another stream: drain before replacing it
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        int rc = ensure(ctx, (void**)&ctx->d_prog, &ctx->d_prog_cap, prog.size() * sizeof(uint32_t));
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->d_prog, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ctx->prog_variant = variant;
+        ctx->prog_len = len;
+        ctx->prog_calls = (unsigned)prog.size();
+    }
+    HIP_TRY(ctx, launch_crypt(decrypt, ctx->d_tab, tag_arg(tag), d_in, d_secrets, d_nonces, (unsigned)len, d_out, d_ok, n, ctx->d_prog,
+                              ctx->prog_calls, st));
     return P252_OK;
 }
 
-int p252_encrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_messages, const void* d_secrets,
+int p252_encrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4], const void* d_messages, const void* d_secrets,
                               const void* d_nonces, size_t len, void* d_ciphers, size_t n, void* hip_stream) {
-    return crypt_device(ctx, false, tag, d_messages, d_secrets, d_nonces, len, d_ciphers, nullptr, n, hip_stream);
+    return crypt_device(ctx, variant, false, tag, d_messages, d_secrets, d_nonces, len, d_ciphers, nullptr, n, hip_stream);
 }
 
-int p252_decrypt_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
+int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
                               const void* d_nonces, size_t len, void* d_messages, void* d_ok, size_t n, void* hip_stream) {
-    return crypt_device(ctx, true, tag, d_ciphers, d_secrets, d_nonces, len, d_messages, d_ok, n, hip_stream);
+    return crypt_device(ctx, variant, true, tag, d_ciphers, d_secrets, d_nonces, len, d_messages, d_ok, n, hip_stream);
 }
 
-static int crypt_host(p252_ctx* ctx, bool decrypt, const uint64_t tag[4], const uint64_t* in, const uint64_t* secrets,
+static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t tag[4], const uint64_t* in, const uint64_t* secrets,
                       const uint64_t* nonces, size_t len, uint64_t* out, uint8_t* ok, size_t n) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (!crypt_variant_ok(variant)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: unknown variant");
     if (len == 0) return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "encrypt/decrypt: empty message");
     if (n == 0) return P252_OK;
     if (!tag || !in || !secrets || !nonces || !out || (decrypt && !ok))
@@ -497,42 +544,29 @@ static int crypt_host(p252_ctx* ctx, bool decrypt, const uint64_t tag[4], const 
     HIP_TRY(ctx, hipMemcpy(di, in, in_b, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(di + in_b, secrets, sec_b, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(di + in_b + sec_b, nonces, non_b, hipMemcpyHostToDevice));
-    rc = crypt_device(ctx, decrypt, tag, di, di + in_b, di + in_b + sec_b, len, dout, dout + out_b, n, nullptr);
+    rc = crypt_device(ctx, variant, decrypt, tag, di, di + in_b, di + in_b + sec_b, len, dout, dout + out_b, n, nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy(out, dout, out_b, hipMemcpyDeviceToHost));
     if (decrypt) HIP_TRY(ctx, hipMemcpy(ok, dout + out_b, n, hipMemcpyDeviceToHost));
     return P252_OK;
 }
 
-int p252_encrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* messages, const uint64_t* secrets,
+int p252_encrypt_batch(p252_ctx* ctx, int variant, const uint64_t tag[4], const uint64_t* messages, const uint64_t* secrets,
                        const uint64_t* nonces, size_t len, uint64_t* ciphers, size_t n) {
-    return crypt_host(ctx, false, tag, messages, secrets, nonces, len, ciphers, nullptr, n);
+    return crypt_host(ctx, variant, false, tag, messages, secrets, nonces, len, ciphers, nullptr, n);
 }
 
-int p252_decrypt_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* ciphers, const uint64_t* secrets,
+int p252_decrypt_batch(p252_ctx* ctx, int variant, const uint64_t tag[4], const uint64_t* ciphers, const uint64_t* secrets,
                        const uint64_t* nonces, size_t len, uint64_t* messages, uint8_t* ok, size_t n) {
-    return crypt_host(ctx, true, tag, ciphers, secrets, nonces, len, messages, ok, n);
+    return crypt_host(ctx, variant, true, tag, ciphers, secrets, nonces, len, messages, ok, n);
 }
 
-// UNPINNED: tag of the encryption io-pattern [Absorb(2)+Absorb(1) -> Absorb(3), {Squeeze(c), Absorb(c)}*, Squeeze(1)]
-int p252_encryption_tag(size_t message_len, uint64_t tag_out[4]) {
-    if (!tag_out) return P252_ERR_INVALID_ARGUMENT;
-    if (message_len == 0) return P252_ERR_INVALID_IO_PATTERN;
-    if (message_len >= 0x80000000ULL) return P252_ERR_INVALID_ARGUMENT;
+// shared by p252_tag and p252_encryption_tag: tag = hash_to_scalar(io-words (BE u32) || domain separator (BE u64)),
+// hash_to_scalar = BLAKE2b-512 read as a 512-bit little-endian integer mod p.  UNPINNED recipe (header).
+static void tag_from_words(const std::vector<uint32_t>& words, uint64_t sep, uint64_t tag_out[4]) {
     std::vector<uint8_t> buf;
-    auto word = [&](uint32_t w) {
+    for (uint32_t w : words)
         for (int b = 0; b < 4; ++b) buf.push_back((uint8_t)(w >> (24 - 8 * b)));
-    };
-    word(0x80000000u | 3u);
-    for (size_t left = message_len; left;) {
-        const uint32_t c = left < 4 ? (uint32_t)left : 4u;
-        word(c);
-        word(0x80000000u | c);
-        left -= c;
-    }
-    word(1);
-    uint64_t sep = 0;
-    p252_domain_separator(P252_DOMAIN_ENCRYPTION, &sep);
     for (int b = 0; b < 8; ++b) buf.push_back((uint8_t)(sep >> (56 - 8 * b)));
     uint8_t h[64];
     blake2b_512(buf.data(), buf.size(), h);
@@ -543,6 +577,27 @@ int p252_encryption_tag(size_t message_len, uint64_t tag_out[4]) {
     }
     FrHost r = FrHost::from_raw(lo) + FrHost::from_raw(hi) * FrHost::pow2(256);
     std::memcpy(tag_out, r.l, 32);
+}
+
+// UNPINNED: tag of the encryption io-pattern of `variant` (adjacent calls of one kind aggregated, as dusk-safe does)
+int p252_encryption_tag(int variant, size_t message_len, uint64_t tag_out[4]) {
+    if (!tag_out || !crypt_variant_ok(variant)) return P252_ERR_INVALID_ARGUMENT;
+    if (message_len == 0) return P252_ERR_INVALID_IO_PATTERN;
+    if (message_len >= 0x1ffffff0ULL) return P252_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> words;
+    int prev_absorb = -1;
+    for (uint32_t c : crypt_program(variant, message_len)) {
+        const uint32_t kind = c >> 29, n = c & 0x1fffffffu;
+        const int is_absorb = kind == 0 || kind == 1 || kind == 3;
+        if (!words.empty() && is_absorb == prev_absorb)
+            words.back() += n;
+        else
+            words.push_back((is_absorb ? 0x80000000u : 0u) | n);
+        prev_absorb = is_absorb;
+    }
+    uint64_t sep = 0;
+    p252_domain_separator(P252_DOMAIN_ENCRYPTION, &sep);
+    tag_from_words(words, sep, tag_out);
     return P252_OK;
 }
 
@@ -604,23 +659,9 @@ int p252_tag(int domain, const size_t* absorb_lens, size_t n_absorbs, size_t out
     if (absorbed >= 0x80000000ULL || out_len >= 0x80000000ULL) return P252_ERR_INVALID_ARGUMENT;
     // tag input: aggregated io-pattern words (big-endian u32, absorb flagged by the top bit), then
     // the domain separator as a big-endian u64
-    const uint32_t words[2] = {0x80000000u | (uint32_t)absorbed, (uint32_t)out_len};
-    uint8_t buf[16];
-    for (int w = 0; w < 2; ++w)
-        for (int b = 0; b < 4; ++b) buf[4 * w + b] = (uint8_t)(words[w] >> (24 - 8 * b));
     uint64_t sep = 0;
     p252_domain_separator(domain, &sep);
-    for (int b = 0; b < 8; ++b) buf[8 + b] = (uint8_t)(sep >> (56 - 8 * b));
-    uint8_t h[64];
-    blake2b_512(buf, sizeof buf, h);
-    // 512-bit little-endian integer mod p:  lo + hi * 2^256
-    uint64_t lo[4], hi[4];
-    for (int k = 0; k < 4; ++k) {
-        lo[k] = u64_from_buffer(h, 8 * k);
-        hi[k] = u64_from_buffer(h, 32 + 8 * k);
-    }
-    FrHost r = FrHost::from_raw(lo) + FrHost::from_raw(hi) * FrHost::pow2(256);
-    std::memcpy(tag_out, r.l, 32);
+    tag_from_words({0x80000000u | (uint32_t)absorbed, (uint32_t)out_len}, sep, tag_out);
     return P252_OK;
 }
 

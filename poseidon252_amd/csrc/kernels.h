@@ -22,8 +22,10 @@ hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* chi
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
                          unsigned out_len, void* out, size_t n, hipStream_t st);
 
+// prog: device array of n_calls sponge-call words (kind << 29 | len), see k_crypt
 hipError_t launch_crypt(bool decrypt, const int32_t* tab, const TagArg& tag, const void* in, const void* secrets,
-                        const void* nonces, unsigned len, void* out, void* flags, size_t n, hipStream_t st);
+                        const void* nonces, unsigned len, void* out, void* flags, size_t n, const uint32_t* prog,
+                        unsigned n_calls, hipStream_t st);
 hipError_t launch_truncate250(const void* in, void* out, size_t n, hipStream_t st);
 hipError_t launch_merkle4_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings,
                                const void* positions, unsigned depth, void* roots, size_t n, hipStream_t st);

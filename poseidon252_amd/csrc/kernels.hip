@@ -117,61 +117,94 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
     }
 }
 
-// ---- batched encryption / decryption (src/encryption.rs:62-95 -> dusk_safe::encrypt / decrypt; the
-// construction is restated from SAFE, UNPINNED like the tag — DESIGN.md §5).  Sponge in duplex use:
-// state = [tag, secret.u, secret.v, nonce, 0]; per chunk of <= 4 elements: permute, mask = state[1..],
-// cipher = message + mask, message absorbed (state[1+k] becomes cipher_k); final permute, MAC = state[1].
-// Encrypt: in = messages[n][len], out = ciphers[n][len+1].  Decrypt: in = ciphers[n][len+1],
-// out = messages[n][len], flags[i] = 1 iff the recomputed MAC equals cipher[len] (else DecryptionFailed). ----
+// ---- batched encryption / decryption (src/encryption.rs:62-95 -> dusk_safe::encrypt / decrypt) ----
+// dusk-safe is not vendored in the reference and its encrypt() is pinned by no reference value, so the
+// kernel does not hard-wire a construction: it INTERPRETS the sponge-call sequence the host hands it (api.cpp
+// crypt_program(): one word per call, kind << 29 | len) on dusk-safe's sponge state machine (pinned
+// by the reference KAT): absorb(e): pos_absorb == 4 -> permute, pos_absorb = 0; state[1 + pos_absorb] += e;
+// after an absorb call pos_squeeze = 4.  squeeze: pos_squeeze == 4 -> permute, both positions = 0; emit
+// state[1 + pos_squeeze].  Every position is wave-uniform, so all of this is scalar control flow around ONE inlined
+// permutation.  Call kinds: 0 absorb the 2 secret scalars, 1 absorb the nonce, 2 squeeze `len` masks and apply them to
+// the next `len` message elements (encrypt: cipher = message + mask; decrypt: message = cipher - mask, scalar.rs:67-74),
+// 3 absorb the next `len` PLAINTEXT elements (decrypt reads back what it wrote), 4 squeeze the MAC (encrypt: stored
+// as cipher[len]; decrypt: compared with it, scalar.rs:76-79 -> flags[i], 0 = Error::DecryptionFailed).
+// Encrypt: in = messages[n][len], out = ciphers[n][len+1].  Decrypt: in = ciphers[n][len+1], out = messages[n][len].
+__device__ __forceinline__ E29 lane_get(const E29 s[WIDTH], unsigned pos) {
+    switch (pos) {  // pos is wave-uniform: a scalar branch, never a per-lane select
+        case 0: return s[1];
+        case 1: return s[2];
+        case 2: return s[3];
+        default: return s[4];
+    }
+}
+__device__ __forceinline__ void lane_add(E29 s[WIDTH], unsigned pos, const E29& x) {
+    switch (pos) {
+        case 0: add_e(s[1], x); break;
+        case 1: add_e(s[2], x); break;
+        case 2: add_e(s[3], x); break;
+        default: add_e(s[4], x); break;
+    }
+}
+
 template <bool DECRYPT>
 __global__ void __launch_bounds__(P252_BLOCK) k_crypt(const int32_t* __restrict__ tab, TagArg tag,
                                                       const Scalar32* __restrict__ in,
                                                       const Scalar32* __restrict__ secrets,
                                                       const Scalar32* __restrict__ nonces, unsigned len,
-                                                      Scalar32* __restrict__ out, uint8_t* __restrict__ flags,
-                                                      size_t n) {
+                                                      Scalar32* out, uint8_t* __restrict__ flags, size_t n,
+                                                      const uint32_t* __restrict__ prog, unsigned n_calls) {
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (idx >= n) return;
     const Scalar32* my_in = in + idx * (DECRYPT ? len + 1 : len);
     Scalar32* my_out = out + idx * (DECRYPT ? len : len + 1);
     E29 s[WIDTH];
     s[0] = from_mont4(tag.w);
-    s[1] = load_scalar(secrets + 2 * idx);
-    s[2] = load_scalar(secrets + 2 * idx + 1);
-    s[3] = load_scalar(nonces + idx);
-    s[4] = e29_zero();
-    const unsigned chunks = (len + 3) / 4;
-#pragma unroll 1
-    for (unsigned it = 0; it <= chunks; ++it) {
-        hades_permute<0x1fu>(s, tab);
-        if (it < chunks) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned e = it * 4 + k;
-                if (e < len) {
-                    const E29 x = load_scalar(my_in + e);
-                    if (!DECRYPT) {
-                        add_e(s[1 + k], x);  // cipher_k = mask_k + message_k, and it IS the absorbed state
-                        store_scalar(my_out + e, s[1 + k]);
-                    } else {
-                        E29 m = x;
-                        sub_e(m, s[1 + k]);  // message_k = cipher_k - mask_k
-                        store_scalar(my_out + e, m);
-                        s[1 + k] = x;        // mask_k + message_k == cipher_k
-                    }
+    for (int k = 1; k < WIDTH; ++k) s[k] = e29_zero();
+    unsigned pos_absorb = 0, pos_squeeze = 0, masked = 0, absorbed = 0;
+#pragma unroll 1
+    for (unsigned ci = 0; ci < n_calls; ++ci) {
+        const unsigned kind = prog[ci] >> 29, cnt = prog[ci] & 0x1fffffffu;
+        const bool is_absorb = kind == 0 || kind == 1 || kind == 3;
+#pragma unroll 1
+        for (unsigned e = 0; e < cnt; ++e) {
+            if ((is_absorb ? pos_absorb : pos_squeeze) == 4) {
+                hades_permute<0x1fu>(s, tab);
+                pos_absorb = 0;
+                if (!is_absorb) pos_squeeze = 0;
+            }
+            if (is_absorb) {
+                const Scalar32* src = kind == 0 ? secrets + 2 * idx + e
+                                      : kind == 1 ? nonces + idx
+                                                  : (DECRYPT ? my_out : my_in) + absorbed + e;
+                lane_add(s, pos_absorb, load_scalar(src));  // Safe::add, scalar.rs:33-35
+                ++pos_absorb;
+            } else {
+                const E29 v = lane_get(s, pos_squeeze);
+                ++pos_squeeze;
+                if (kind == 2) {
+                    E29 x = load_scalar(my_in + masked + e);
+                    if (!DECRYPT)
+                        add_e(x, v);  // cipher = message + mask
+                    else
+                        sub_e(x, v);  // message = cipher - mask
+                    store_scalar(my_out + masked + e, x);
+                } else if (!DECRYPT) {
+                    store_scalar(my_out + len, v);
+                } else {
+                    uint32_t w[8];
+                    to_mont4(v, w);
+                    const uint4 lo = *reinterpret_cast<const uint4*>(my_in + len);
+                    const uint4 hi = *(reinterpret_cast<const uint4*>(my_in + len) + 1);
+                    const bool same = w[0] == lo.x && w[1] == lo.y && w[2] == lo.z && w[3] == lo.w && w[4] == hi.x &&
+                                      w[5] == hi.y && w[6] == hi.z && w[7] == hi.w;
+                    flags[idx] = same ? 1 : 0;
                 }
             }
-        } else if (!DECRYPT) {
-            store_scalar(my_out + len, s[1]);
-        } else {
-            uint32_t w[8];
-            to_mont4(s[1], w);
-            const uint4 lo = *reinterpret_cast<const uint4*>(my_in + len);
-            const uint4 hi = *(reinterpret_cast<const uint4*>(my_in + len) + 1);
-            const bool same = w[0] == lo.x && w[1] == lo.y && w[2] == lo.z && w[3] == lo.w && w[4] == hi.x &&
-                              w[5] == hi.y && w[6] == hi.z && w[7] == hi.w;
-            flags[idx] = same ? 1 : 0;
         }
+        if (is_absorb) pos_squeeze = 4;
+        if (kind == 2) masked += cnt;
+        if (kind == 3) absorbed += cnt;
     }
 }
 
@@ -263,18 +296,19 @@ hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, 
 }
 
 hipError_t launch_crypt(bool decrypt, const int32_t* tab, const TagArg& tag, const void* in, const void* secrets,
-                        const void* nonces, unsigned len, void* out, void* flags, size_t n, hipStream_t st) {
+                        const void* nonces, unsigned len, void* out, void* flags, size_t n, const uint32_t* prog,
+                        unsigned n_calls, hipStream_t st) {
     if (n == 0) return hipSuccess;
     if (decrypt)
         hipLaunchKernelGGL(k_crypt<true>, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                            static_cast<const Scalar32*>(in), static_cast<const Scalar32*>(secrets),
                            static_cast<const Scalar32*>(nonces), len, static_cast<Scalar32*>(out),
-                           static_cast<uint8_t*>(flags), n);
+                           static_cast<uint8_t*>(flags), n, prog, n_calls);
     else
         hipLaunchKernelGGL(k_crypt<false>, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                            static_cast<const Scalar32*>(in), static_cast<const Scalar32*>(secrets),
                            static_cast<const Scalar32*>(nonces), len, static_cast<Scalar32*>(out),
-                           static_cast<uint8_t*>(flags), n);
+                           static_cast<uint8_t*>(flags), n, prog, n_calls);
     return hipGetLastError();
 }
 
