@@ -31,8 +31,9 @@
  * fails with P252_ERR_NO_DEVICE / P252_ERR_HIP.
  *
  * Threading: a context is bound to one device and used by one thread at a time; distinct contexts
- * are independent.  Multi-GPU = one process (or thread) and one context per GPU; batches shard with
- * no inter-GPU dependence.
+ * are independent.  Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
+ * or the p252_*_multi entry points below, which take the array of contexts and shard inside the library; batches
+ * shard with no inter-GPU dependence.
  */
 #ifndef POSEIDON252_HIP_H
 #define POSEIDON252_HIP_H
@@ -93,10 +94,11 @@ int p252_merkle2_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leav
                       uint64_t root[4], uint64_t* levels);
 size_t p252_merkle2_levels_len(size_t n_leaves);
 
-/* Page-locked host memory (hipHostMalloc).  The host-buffer entry points pipeline H2D / kernel / D2H
- * over 3 streams for large batches; with buffers from p252_host_alloc the copies run at PCIe speed,
- * with ordinary (pageable) memory the buffers are page-locked for the duration of each call.  NULL on
- * failure. */
+/* Page-locked host memory (hipHostMalloc).  p252_hash_batch pipelines H2D / kernel / D2H for large batches.  With
+ * ordinary (pageable) caller memory — a Rust Vec<BlsScalar> — nothing the caller owns is touched: chunks go through
+ * library-owned page-locked staging lanes (one worker thread, stream and buffer pair per lane; P252_HOST_LANES, default
+ * 8) so that the host copies of one lane overlap the DMA and kernels of the others.  With buffers from p252_host_alloc /
+ * p252_host_register on BOTH sides the copies are zero-copy DMA over 3 streams.  NULL on failure. */
 void* p252_host_alloc(size_t bytes);
 void p252_host_free(void* p);
 /* Page-lock / release a buffer the caller already owns (hipHostRegister / hipHostUnregister) — e.g. a Rust
@@ -166,6 +168,28 @@ int p252_encrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
                               const void* d_nonces, size_t len, void* d_ciphers, size_t n, void* hip_stream);
 int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
                               const void* d_nonces, size_t len, void* d_messages, void* d_ok, size_t n, void* hip_stream);
+
+/* ---- multi-device: an array of contexts, one per GPU.  Shards are contiguous and independent: no
+ * inter-GPU dependence and no collective on the data path.  The calls are synchronous; inside, one host thread drives
+ * each context.  A context may appear only once.  On failure the error text is on ctxs[0] (p252_last_error). ---- */
+/* n digests / sponges, item i of the batch on device floor-split: device t hashes a contiguous n/n_ctx slice (sizes
+ * differ by at most one); per-item results identical to p252_hash_batch. */
+int p252_hash_batch_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
+                          size_t out_len, uint64_t* out, size_t n);
+/* the same on device-resident shards: d_in[t] / d_out[t] live on ctxs[t]'s device and hold n_per_ctx[t] items;
+ * asynchronous on hip_streams[t] (hip_streams == NULL: every device's default stream); p252_sync each context. */
+int p252_hash_batch_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_in, size_t in_len,
+                                 size_t out_len, void* const* d_out, const size_t* n_per_ctx, void* const* hip_streams);
+/* Sharded arity-4 tree (BASELINE configs[4]: 2^27 leaves = 8 x 4^12): device t reduces the t-th contiguous run of
+ * n_leaves / n_ctx leaves — which must be a complete subtree, 4^k leaves — to its root with zero communication; the
+ * n_ctx roots (32 bytes each) are gathered on the host and the <= log4(n_ctx) + 1 top levels (zero-padded per
+ * hash.rs:22-26) are hashed on ctxs[0].  root == p252_merkle4_tree over the concatenation.  Anything else than
+ * n_leaves = n_ctx * 4^k -> P252_ERR_INVALID_ARGUMENT. */
+int p252_merkle4_tree_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                            uint64_t root[4]);
+/* the same with every device's leaves_per_ctx = 4^k leaves already resident at d_leaves[t]; root is written to host memory */
+int p252_merkle4_tree_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,
+                                   size_t leaves_per_ctx, uint64_t root[4]);
 
 /* ---- constant-table exchange (multi-GPU: rank 0 broadcasts its derived table over RCCL, every
  * rank imports it; byte-identical to what p252_create derives locally) ---- */

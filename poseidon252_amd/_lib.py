@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "p252_host_alloc", "p252_host_free", "p252_host_register", "p252_host_unregister", "p252_merkle2_tree", "p252_merkle2_levels_len", "p252_merkle2_tree_device",
     "p252_encryption_tag", "p252_encrypt_batch", "p252_decrypt_batch", "p252_encrypt_batch_device",
     "p252_decrypt_batch_device",
+    "p252_hash_batch_multi", "p252_hash_batch_multi_device", "p252_merkle4_tree_multi", "p252_merkle4_tree_multi_device",
     "p252_tables_size", "p252_tables_export", "p252_tables_import",
     "p252_domain_separator", "p252_check_io_pattern", "p252_tag", "p252_truncate250", "p252_version",
 )
@@ -75,6 +76,11 @@ def lib():
     L.p252_decrypt_batch.argtypes = [_vp, ctypes.c_int, _u64p, _u64p, _u64p, _u64p, _sz, _u64p, _u8p2, _sz]
     L.p252_encrypt_batch_device.argtypes = [_vp, ctypes.c_int, _u64p, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
     L.p252_decrypt_batch_device.argtypes = [_vp, ctypes.c_int, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
+    _vpp = ctypes.POINTER(_vp)
+    L.p252_hash_batch_multi.argtypes = [_vpp, _sz, _u64p, _u64p, _sz, _sz, _u64p, _sz]
+    L.p252_hash_batch_multi_device.argtypes = [_vpp, _sz, _u64p, _vpp, _sz, _sz, _vpp, _szp, _vpp]
+    L.p252_merkle4_tree_multi.argtypes = [_vpp, _sz, _u64p, _u64p, _sz, _u64p]
+    L.p252_merkle4_tree_multi_device.argtypes = [_vpp, _sz, _u64p, _vpp, _sz, _u64p]
     L.p252_host_alloc.argtypes = [_sz]
     L.p252_host_alloc.restype = _vp
     L.p252_host_free.argtypes = [_vp]

@@ -7,12 +7,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/poseidon252_hip.h"
 #include "blake2b.hpp"
+#include "hades29.hpp"
 #include "kernels.h"
 #include "tables.hpp"
 #include "_gen/assets.inc"
@@ -30,7 +33,18 @@ struct p252_ctx {
     size_t d_out_cap = 0;
     void* d_lvl[2] = {nullptr, nullptr};
     size_t d_lvl_cap[2] = {0, 0};
-    hipStream_t streams[3] = {nullptr, nullptr, nullptr};  // host-buffer pipeline (created on first use)
+    hipStream_t streams[3] = {nullptr, nullptr, nullptr};  // host-buffer pipeline over caller-pinned memory (created on first use)
+    // host-buffer pipeline over PAGEABLE caller memory: library-owned page-locked staging, one lane per worker thread
+    // (stream + pinned in/out chunk + device in/out chunk), created on first use and kept
+    struct Lane {
+        hipStream_t st = nullptr;
+        void* h_in = nullptr;
+        void* h_out = nullptr;
+        void* d_in = nullptr;
+        void* d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+    };
+    std::vector<Lane> lanes;
     // encryption: the sponge-call program of the last (variant, message_len) used, uploaded once (k_crypt interprets it)
     uint32_t* d_prog = nullptr;
     size_t d_prog_cap = 0;
@@ -85,10 +99,29 @@ static const std::vector<int32_t>& host_tables() {
 static bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 static const char* const ALIGN_MSG = "device scalar arrays must be 16-byte aligned";
 
+// kernel argument for the tag: the scalar itself and lane 0's first-round S-box output (the digest kernels start there)
 static TagArg tag_arg(const uint64_t tag[4]) {
     TagArg t;
     std::memcpy(t.w, tag, 32);
+    const E29 x0 = hades_pre0(from_mont4(t.w), host_tables().data());
+    for (int k = 0; k < NL; ++k) t.x0[k] = x0.d[k];
     return t;
+}
+
+// runs f(t) for every context index on its own host thread (t = 0 on the calling thread); first failure wins
+template <class F>
+static int for_each_ctx(p252_ctx* const* ctxs, size_t n_ctx, F&& f) {
+    std::vector<int> rcs(n_ctx, P252_OK);
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_ctx; ++t) pool.emplace_back([&, t] { rcs[t] = f(t); });
+    rcs[0] = f(0);
+    for (auto& th : pool) th.join();
+    for (size_t t = 0; t < n_ctx; ++t)
+        if (rcs[t] != P252_OK) {
+            if (t != 0 && ctxs[0]) ctxs[0]->err = "context " + std::to_string(t) + ": " + ctxs[t]->err;  // p252_last_error(ctxs[0])
+            return rcs[t];
+        }
+    return P252_OK;
 }
 
 extern "C" {
@@ -142,6 +175,13 @@ void p252_destroy(p252_ctx* ctx) {
     for (int i = 0; i < 3; ++i)
         if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
     if (ctx->d_prog) (void)hipFree(ctx->d_prog);
+    for (auto& l : ctx->lanes) {
+        if (l.st) (void)hipStreamDestroy(l.st);
+        if (l.h_in) (void)hipHostFree(l.h_in);
+        if (l.h_out) (void)hipHostFree(l.h_out);
+        if (l.d_in) (void)hipFree(l.d_in);
+        if (l.d_out) (void)hipFree(l.d_out);
+    }
     delete ctx;
 }
 
@@ -267,53 +307,137 @@ int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, siz
     return P252_OK;
 }
 
+static bool is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    const bool is = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return is;
+}
+
+// Pageable caller memory (a Rust Vec<BlsScalar>, a numpy array): page-locking it per call costs as much as the transfer
+// (round 1: 1.9e8 digests/s against 4.0e8 from pinned memory), and one thread copying into a staging buffer moves
+// ~10 GB/s where the Merkle4 stream needs ~60.  So the call is split into chunks handled by LANES worker threads, each
+// with its own page-locked staging pair, device chunk pair and stream:  memcpy in -> H2D -> kernel -> D2H -> memcpy out.
+// The host copies of one lane overlap the DMA and kernels of the others; nothing the caller owns is ever registered.
+static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
+                             uint64_t* out, size_t n, size_t chunk) {
+    static const int lanes_wanted = [] {
+        const char* e = std::getenv("P252_HOST_LANES");
+        int v = e ? std::atoi(e) : 8;
+        return v < 1 ? 1 : (v > 32 ? 32 : v);
+    }();
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    const int n_lanes = (int)(n_chunks < (size_t)lanes_wanted ? n_chunks : (size_t)lanes_wanted);
+    if ((int)ctx->lanes.size() < n_lanes) ctx->lanes.resize(n_lanes);
+    const size_t in_chunk_b = chunk * in_len * 32, out_chunk_b = chunk * out_len * 32;
+    for (int l = 0; l < n_lanes; ++l) {
+        p252_ctx::Lane& L = ctx->lanes[l];
+        if (!L.st) HIP_TRY(ctx, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        if (L.in_cap < in_chunk_b) {
+            if (L.h_in) (void)hipHostFree(L.h_in);
+            if (L.d_in) (void)hipFree(L.d_in);
+            L.h_in = L.d_in = nullptr;
+            L.in_cap = 0;
+            HIP_TRY(ctx, hipHostMalloc(&L.h_in, in_chunk_b, hipHostMallocDefault));
+            HIP_TRY(ctx, hipMalloc(&L.d_in, in_chunk_b));
+            L.in_cap = in_chunk_b;
+        }
+        if (L.out_cap < out_chunk_b) {
+            if (L.h_out) (void)hipHostFree(L.h_out);
+            if (L.d_out) (void)hipFree(L.d_out);
+            L.h_out = L.d_out = nullptr;
+            L.out_cap = 0;
+            HIP_TRY(ctx, hipHostMalloc(&L.h_out, out_chunk_b, hipHostMallocDefault));
+            HIP_TRY(ctx, hipMalloc(&L.d_out, out_chunk_b));
+            L.out_cap = out_chunk_b;
+        }
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> status{P252_OK};
+    std::mutex err_mu;
+    std::string err;
+    const TagArg targ = tag_arg(tag);
+    const bool single = in_len == 4 && out_len == 1, pair = in_len == 2 && out_len == 1;
+    auto work = [&](int l) {
+        p252_ctx::Lane& L = ctx->lanes[l];
+        auto bad = [&](const char* what, hipError_t e) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (status.load() == P252_OK) {
+                status.store(P252_ERR_HIP);
+                err = std::string(what) + ": " + hipGetErrorString(e);
+            }
+        };
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) return bad("hipSetDevice", e);
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= n_chunks || status.load() != P252_OK) return;
+            const size_t off = c * chunk, cnt = n - off < chunk ? n - off : chunk;
+            std::memcpy(L.h_in, reinterpret_cast<const char*>(in) + off * in_len * 32, cnt * in_len * 32);
+            e = hipMemcpyAsync(L.d_in, L.h_in, cnt * in_len * 32, hipMemcpyHostToDevice, L.st);
+            if (e != hipSuccess) return bad("H2D", e);
+            if (single)
+                e = launch_merkle4(ctx->d_tab, targ, L.d_in, 4 * cnt, L.d_out, cnt, L.st);
+            else if (pair)
+                e = launch_merkle4(ctx->d_tab, targ, L.d_in, 2 * cnt, L.d_out, cnt, L.st, 2);
+            else
+                e = launch_sponge(ctx->d_tab, targ, L.d_in, (unsigned)in_len, (unsigned)out_len, L.d_out, cnt, L.st);
+            if (e != hipSuccess) return bad("kernel launch", e);
+            e = hipMemcpyAsync(L.h_out, L.d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, L.st);
+            if (e != hipSuccess) return bad("D2H", e);
+            e = hipStreamSynchronize(L.st);
+            if (e != hipSuccess) return bad("stream sync", e);
+            std::memcpy(reinterpret_cast<char*>(out) + off * out_len * 32, L.h_out, cnt * out_len * 32);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int l = 1; l < n_lanes; ++l) pool.emplace_back(work, l);
+    work(0);
+    for (auto& t : pool) t.join();
+    if (status.load() != P252_OK) return fail(ctx, status.load(), err);
+    return P252_OK;
+}
+
 int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
                     uint64_t* out, size_t n) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (in_len == 0 || out_len == 0)
         return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "hash: in_len and out_len must be > 0");
+    if (in_len > 0x7fffffffu || out_len > 0x7fffffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "hash: length too large");
     if (n == 0) return P252_OK;
     if (!tag || !in || !out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "hash: NULL buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = n * in_len * 32, out_bytes = n * out_len * 32;
-    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
-    if (rc) return rc;
-    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
-    if (rc) return rc;
-    // Large batches are pipelined: chunks round-robin over 3 streams so that the H2D copy of chunk c+1,
-    // the kernel of chunk c and the D2H copy of chunk c-1 overlap (the call stays synchronous).
-    // P252_HOST_PIPELINE: 0 = serial copies, 1 = pipelined from pageable memory, 2 (default) = pipelined
-    // with the caller's buffers page-locked (hipHostRegister) for the duration of the call.
+    // P252_HOST_PIPELINE (developer switch): 0 = one serial copy each way, anything else (default) = pipelined
     static const int mode = [] {
         const char* e = std::getenv("P252_HOST_PIPELINE");
         return e ? std::atoi(e) : 2;
     }();
     const size_t chunk_bytes_target = (size_t)16 << 20;
-    size_t chunk = chunk_bytes_target / (in_len * 32);
+    size_t chunk = chunk_bytes_target / ((in_len > out_len ? in_len : out_len) * 32);
     if (chunk < 4096) chunk = 4096;
     chunk &= ~(size_t)255;
     if (mode == 0 || n < 2 * chunk) {
+        int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
+        if (rc) return rc;
+        rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
+        if (rc) return rc;
         HIP_TRY(ctx, hipMemcpy(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice));
         rc = p252_hash_batch_device(ctx, tag, ctx->d_in, in_len, out_len, ctx->d_out, n, nullptr);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost));
         return P252_OK;
     }
+    // caller memory that is not page-locked on BOTH sides goes through the library's own staging lanes
+    if (!is_pinned(in) || !is_pinned(out)) return hash_batch_staged(ctx, tag, in, in_len, out_len, out, n, chunk);
+    // page-locked on both sides (p252_host_alloc / p252_host_register): zero-copy DMA, chunks round-robin over 3
+    // streams so that the H2D copy of chunk c+1, the kernel of chunk c and the D2H copy of chunk c-1 overlap
+    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
+    if (rc) return rc;
     for (int i = 0; i < 3; ++i)
         if (!ctx->streams[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking));
-    bool reg_in = false, reg_out = false;
-    if (mode == 2) {
-        auto pinned = [](const void* p) {
-            hipPointerAttribute_t a;
-            const bool is = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
-            (void)hipGetLastError();
-            return is;
-        };
-        // buffers from p252_host_alloc are already page-locked; anything else is pinned for this call
-        if (!pinned(in)) reg_in = hipHostRegister(const_cast<uint64_t*>(in), in_bytes, hipHostRegisterDefault) == hipSuccess;
-        if (!pinned(out)) reg_out = hipHostRegister(out, out_bytes, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();  // registration is an optimisation: a failure only means slower copies
-    }
     int status = P252_OK;
     std::string err;
     size_t c = 0;
@@ -336,8 +460,6 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
         hipError_t e = hipStreamSynchronize(ctx->streams[i]);
         if (e != hipSuccess && status == P252_OK) { status = P252_ERR_HIP; err = std::string("stream sync: ") + hipGetErrorString(e); }
     }
-    if (reg_in) (void)hipHostUnregister(const_cast<uint64_t*>(in));
-    if (reg_out) (void)hipHostUnregister(out);
     if (status != P252_OK) return fail(ctx, status, err);
     return P252_OK;
 }
@@ -602,6 +724,111 @@ int p252_encryption_tag(int variant, size_t message_len, uint64_t tag_out[4]) {
 }
 
 // ------------------------------------------------------------------------------------------
+// multi-device entry points (SURVEY §8(b) sketch, §8(e)): an array of contexts, one per GPU.  Shards are contiguous and
+// independent — no inter-GPU dependence, no collective on the data path; the only exchange of the sharded tree is the
+// 32-byte subtree root of every device, gathered by the host.  One host thread per context for the duration of the call.
+// ------------------------------------------------------------------------------------------
+static bool power_of_4(size_t v) {
+    if (v == 0 || (v & (v - 1))) return false;
+    int tz = 0;
+    while (!((v >> tz) & 1)) ++tz;
+    return (tz & 1) == 0;
+}
+
+static int check_ctxs(p252_ctx* const* ctxs, size_t n_ctx) {
+    if (!ctxs || n_ctx == 0) return P252_ERR_INVALID_ARGUMENT;
+    for (size_t t = 0; t < n_ctx; ++t)
+        if (!ctxs[t]) return P252_ERR_INVALID_ARGUMENT;
+    for (size_t a = 0; a < n_ctx; ++a)  // a context is used by one thread at a time: no duplicates
+        for (size_t b = a + 1; b < n_ctx; ++b)
+            if (ctxs[a] == ctxs[b]) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "multi: the same context appears twice");
+    return P252_OK;
+}
+
+int p252_hash_batch_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
+                          size_t out_len, uint64_t* out, size_t n) {
+    int rc = check_ctxs(ctxs, n_ctx);
+    if (rc) return rc;
+    if (in_len == 0 || out_len == 0) return fail(ctxs[0], P252_ERR_INVALID_IO_PATTERN, "hash: in_len and out_len must be > 0");
+    if (n == 0) return P252_OK;
+    if (!tag || !in || !out) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "hash: NULL buffer");
+    // contiguous shards, sizes differing by at most one item
+    const size_t base = n / n_ctx, rem = n % n_ctx;
+    return for_each_ctx(ctxs, n_ctx, [&](size_t t) {
+        const size_t lo = t * base + (t < rem ? t : rem), cnt = base + (t < rem ? 1 : 0);
+        return p252_hash_batch(ctxs[t], tag, in + lo * in_len * 4, in_len, out_len, out + lo * out_len * 4, cnt);
+    });
+}
+
+int p252_hash_batch_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_in, size_t in_len,
+                                 size_t out_len, void* const* d_out, const size_t* n_per_ctx, void* const* hip_streams) {
+    int rc = check_ctxs(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!d_in || !d_out || !n_per_ctx) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "hash_multi_device: NULL array");
+    for (size_t t = 0; t < n_ctx; ++t) {  // launches are asynchronous: a plain loop, no threads needed
+        rc = p252_hash_batch_device(ctxs[t], tag, d_in[t], in_len, out_len, d_out[t], n_per_ctx[t], hip_streams ? hip_streams[t] : nullptr);
+        if (rc) {
+            if (t) ctxs[0]->err = "context " + std::to_string(t) + ": " + ctxs[t]->err;
+            return rc;
+        }
+    }
+    return P252_OK;
+}
+
+static int tree_top(p252_ctx* ctx0, const uint64_t tag[4], const std::vector<uint64_t>& roots, size_t n_ctx, uint64_t root[4]) {
+    if (n_ctx == 1) {
+        std::memcpy(root, roots.data(), 32);
+        return P252_OK;
+    }
+    return p252_merkle4_tree(ctx0, tag, roots.data(), n_ctx, root, nullptr);  // <= log4(n_ctx) + 1 tiny levels, zero-padded
+}
+
+int p252_merkle4_tree_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
+                            uint64_t root[4]) {
+    int rc = check_ctxs(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!tag || !leaves || !root) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi: NULL buffer");
+    if (n_leaves == 0 || n_leaves % n_ctx || !power_of_4(n_leaves / n_ctx))
+        return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT,
+                    "merkle_tree_multi: every device must own a complete subtree (n_leaves = n_ctx * 4^k)");
+    const size_t m = n_leaves / n_ctx;
+    std::vector<uint64_t> roots(4 * n_ctx);
+    rc = for_each_ctx(ctxs, n_ctx, [&](size_t t) { return p252_merkle4_tree(ctxs[t], tag, leaves + t * m * 4, m, &roots[4 * t], nullptr); });
+    if (rc) return rc;
+    return tree_top(ctxs[0], tag, roots, n_ctx, root);
+}
+
+int p252_merkle4_tree_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,
+                                   size_t leaves_per_ctx, uint64_t root[4]) {
+    int rc = check_ctxs(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!tag || !d_leaves || !root) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi_device: NULL buffer");
+    if (!power_of_4(leaves_per_ctx))
+        return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi_device: every device must own a complete subtree (4^k leaves)");
+    // every device reduces its resident subtree (asynchronous launches on its own default stream) ...
+    std::vector<void*> d_roots(n_ctx, nullptr);
+    for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) {
+        p252_ctx* c = ctxs[t];
+        if (hipSetDevice(c->device) != hipSuccess) { rc = fail(c, P252_ERR_HIP, "hipSetDevice"); break; }
+        rc = ensure(c, &c->d_out, &c->d_out_cap, 32);
+        if (rc == P252_OK) rc = merkle_tree_device(c, 4, tag, d_leaves[t], leaves_per_ctx, c->d_out, nullptr, nullptr);
+        d_roots[t] = c->d_out;
+    }
+    // ... then the only exchange step of the path: 32 bytes per device to the host
+    std::vector<uint64_t> roots(4 * n_ctx);
+    for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) {
+        p252_ctx* c = ctxs[t];
+        if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(&roots[4 * t], d_roots[t], 32, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(c, P252_ERR_HIP, "merkle_tree_multi_device: root copy failed");
+    }
+    if (rc) {
+        if (ctxs[0]->err.empty()) ctxs[0]->err = "merkle_tree_multi_device failed on another context";
+        return rc;
+    }
+    return tree_top(ctxs[0], tag, roots, n_ctx, root);
+}
+
+// ------------------------------------------------------------------------------------------
 // constant-table exchange
 // ------------------------------------------------------------------------------------------
 size_t p252_tables_size(void) { return (size_t)Tab29Layout::TOTAL * sizeof(int32_t); }
@@ -615,6 +842,11 @@ int p252_tables_export(p252_ctx* ctx, void* host_buf, size_t len) {
 
 int p252_tables_import(p252_ctx* ctx, const void* host_buf, size_t len) {
     if (!ctx || !host_buf || len != p252_tables_size()) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "tables_import: bad args");
+    // The table is a pure function of arc.bin / mds.bin, which are compiled in: anything else than what this library
+    // derives itself (with its Cauchy-structure and column-bound checks) is a corrupted or mismatched broadcast and
+    // would give silently wrong digests — refuse it.
+    if (std::memcmp(host_buf, host_tables().data(), len) != 0)
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "tables_import: the table differs from the one this library derives from its arc.bin / mds.bin");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpy(ctx->d_tab, host_buf, len, hipMemcpyHostToDevice));
     std::memcpy(ctx->h_tab.data(), host_buf, len);

@@ -144,12 +144,24 @@ P252_HD void acc_mul(A29& t, const E29& a, BP b) {
     }
 }
 
+// 2 x as an ADD: on gfx950 v_add_u32 issues at the 2-cycle rate, v_lshlrev_b32 (what x * 2 compiles to) at the 4-cycle
+// rate (profiles/r02_valu_rates_gfx950.txt) — 1,600 doublings per permutation.
+P252_HD int32_t twice(int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x * 2;
+#endif
+}
+
 // t += a * a  (45 products instead of 81)
 P252_HD void acc_sqr(A29& t, const E29& a) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         t.c[2 * i] += (int64_t)a.d[i] * (int64_t)a.d[i];
-        const int64_t a2 = (int64_t)(a.d[i] * 2);  // |d| < 2^29 -> fits int32
+        const int64_t a2 = (int64_t)twice(a.d[i]);  // |d| < 2^29 -> fits int32
 #pragma unroll
         for (int j = i + 1; j < NL; ++j) t.c[i + j] += a2 * (int64_t)a.d[j];
     }

@@ -291,14 +291,16 @@ P252_HD E29 small_mul_add(const E29& x, int32_t m, TP add) {
 // values are exactly the two history rings), then the exit rows (exit_row).  Full round 3 is the entry: its linear
 // layer produces U_1 and the virtual history (entry_row, small_mul_add).  OUT_ROWS: bit k set = lane k of the result is needed (a
 // Merkle4 digest needs lane 1 only: the multiplication by F is done for that lane alone).
-template <unsigned OUT_ROWS = 0x1fu, class TP>
+// PRE0: s[0] already holds lane 0's S-box OUTPUT of the first round (hades_pre0 below): the capacity lane of a digest is
+// the tag, the same for every item of a batch, so that S-box is computed once on the host and travels as a kernel argument.
+template <unsigned OUT_ROWS = 0x1fu, bool PRE0 = false, class TP>
 P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
     static_assert(PARTIAL_ROUNDS % HIST == 0, "60 ARMA rounds must split evenly");
     const RK K = make_rk();  // bias 2^31 / constant 8 of the wide Montgomery step (fr29.hpp), in registers throughout
 #pragma unroll
-    for (int i = 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
+    for (int i = PRE0 ? 1 : 0; i < WIDTH; ++i) add_c(s[i], tab + Lay::C_FIRST + i * NL);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
 #pragma unroll 1
@@ -306,10 +308,19 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
             const TP kap = tab + Lay::AI_KAPPA + f * WIDTH * NL;
             E29 x[WIDTH];
 #pragma unroll
-            for (int j = 0; j < WIDTH; ++j) x[j] = sbox_w(s[j], K);
+            for (int j = 1; j < WIDTH; ++j) x[j] = sbox_w(s[j], K);
+            if (PRE0 && f == 0)  // (wave-uniform) first round of a digest: lane 0's S-box output came with the launch
+                x[0] = s[0];
+            else
+                x[0] = sbox_w(s[0], K);
             if (f == RF - 1) {  // the linear layer of round 3 is the entry below: hand over the S-box outputs
 #pragma unroll
                 for (int i = 0; i < WIDTH; ++i) s[i] = x[i];
+            } else if (OUT_ROWS != 0x1fu && f == 2 * RF - 1) {
+                // last round of a digest: only the rows that are squeezed (their own block: one row of products each)
+#pragma unroll
+                for (int i = 0; i < WIDTH; ++i)
+                    if ((OUT_ROWS >> i) & 1u) s[i] = int_row(x, tab + Lay::INT_N + i, kap + i * NL);
             } else {
 #pragma unroll
                 for (int i = 0; i < WIDTH; ++i) s[i] = int_row(x, tab + Lay::INT_N + i, kap + i * NL);
@@ -358,6 +369,18 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
             s[i] = mul_c(s[i], tab + Lay::AI_F);
             sched_fence();
         }
+}
+
+// Lane 0's S-box output of the first round for the capacity element `tag` (host side, once per launch): exactly what
+// hades_permute computes for lane 0 before its first linear layer.  Any representative of the residue class would do
+// (every later step is exact modular arithmetic on lazy residues); this is the one the device itself would produce.
+template <class TP>
+P252_HD E29 hades_pre0(const E29& tag, TP tab) {
+    typedef Tab29Layout Lay;
+    const RK K = make_rk();
+    E29 t = tag;
+    add_c(t, tab + Lay::C_FIRST);
+    return sbox_w(t, K);
 }
 
 }  // namespace p252

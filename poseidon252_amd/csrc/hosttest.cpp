@@ -117,6 +117,20 @@ void ht_permute29_sched(const uint64_t* states, uint64_t* out, size_t n, int sch
 }
 void ht_permute29(const uint64_t* states, uint64_t* out, size_t n) { ht_permute29_sched(states, out, n, 0); }
 
+// the Merkle4-digest path exactly as k_merkle4 runs it: lane 0 enters after its first S-box (hades_pre0, computed once
+// per tag), only row 1 of the last linear layer is formed (OUT_ROWS = 0x02)
+void ht_merkle4_digest29(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n) {
+    const int32_t* tab = tab29().data();
+    const E29 x0 = hades_pre0(from_mont4(reinterpret_cast<const uint32_t*>(tag)), tab);
+    for (size_t i = 0; i < n; ++i) {
+        E29 s[WIDTH];
+        s[0] = x0;
+        for (int k = 0; k < 4; ++k) s[1 + k] = from_mont4(reinterpret_cast<const uint32_t*>(children + (i * 4 + k) * 4));
+        hades_permute<0x02u, true>(s, tab);
+        to_mont4(s[1], reinterpret_cast<uint32_t*>(out + i * 4));
+    }
+}
+
 // Static worst-case |column| of every lazy accumulation in the schedules, assuming state digits
 // < 2^29 (top digit < 2^24) and using the ACTUAL table constants; includes the < 2^61 the
 // reduction itself adds.  Must stay below 2^63 (tests/test_host_arith.py).

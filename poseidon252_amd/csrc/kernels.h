@@ -11,9 +11,11 @@
 
 namespace p252 {
 
-// the sponge tag (state[0]) travels as a kernel argument: 8 x u32 = one BlsScalar
+// the sponge tag (state[0]) travels as a kernel argument: 8 x u32 = one BlsScalar, plus (for the single-permutation
+// digest kernels) the nine digits of its first-round S-box output, computed once per launch on the host (hades_pre0)
 struct TagArg {
     uint32_t w[8];
+    int32_t x0[9];
 };
 
 hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t n, hipStream_t st);

@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4(const in
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (idx >= n) return;
     E29 s[WIDTH];
-    s[0] = from_mont4(tag.w);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) s[0].d[k] = tag.x0[k];  // lane 0 enters after its first S-box (hades_permute PRE0)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const size_t c = idx * arity + k;
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4(const in
         else
             s[1 + k] = e29_zero();
     }
-    hades_permute<0x02u>(s, tab);  // only lane 1 is squeezed
+    hades_permute<0x02u, true>(s, tab);  // only lane 1 is squeezed
     store_scalar(out + idx, s[1]);
 }
 
@@ -247,7 +248,8 @@ __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path(con
     for (unsigned l = 0; l < depth; ++l) {
         const unsigned p = pos[l] & 3u;
         E29 s[WIDTH];
-        s[0] = from_mont4(tag.w);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) s[0].d[k] = tag.x0[k];
         const E29 a = load_scalar(sib + l * 3 + 0), b = load_scalar(sib + l * 3 + 1), c = load_scalar(sib + l * 3 + 2);
         // children = siblings with `cur` inserted at slot p (per-lane select, no divergence)
 #pragma unroll
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path(con
             s[3].d[k] = p == 2 ? cur.d[k] : (p < 2 ? b.d[k] : c.d[k]);
             s[4].d[k] = p == 3 ? cur.d[k] : c.d[k];
         }
-        hades_permute<0x02u>(s, tab);
+        hades_permute<0x02u, true>(s, tab);
         cur = s[1];
     }
     store_scalar(roots + idx, cur);

@@ -25,8 +25,10 @@ def _dist():
 
 
 def broadcast_tables(ctx, device=None):
-    """rank 0 -> all: the device constant table.  Returns True if the received table equals the locally
-    derived one (always expected)."""
+    """rank 0 -> all: the device constant table (BASELINE.json north_star: RCCL broadcast of constants).  The table is
+    a pure function of the arc.bin / mds.bin compiled into the library, so the received bytes must equal the local
+    derivation: a mismatch (corrupted broadcast, ranks running different builds) RAISES — p252_tables_import itself
+    refuses such a table — instead of hashing with unchecked constants.  Returns True."""
     import torch
     dist = _dist()
     local = ctx.tables_export()
@@ -36,9 +38,11 @@ def broadcast_tables(ctx, device=None):
     if dist.is_initialized():
         dist.broadcast(t, src=0)
     got = t.cpu().numpy()
-    same = bool(np.array_equal(got, local))
-    ctx.tables_import(got)
-    return same
+    if not np.array_equal(got, local):
+        raise RuntimeError("constant table received from rank 0 differs from the locally derived one "
+                           "(corrupted broadcast or mismatched library builds)")
+    ctx.tables_import(got)  # validated again inside the library (byte-identical to its own derivation)
+    return True
 
 
 def is_power_of_4(n):

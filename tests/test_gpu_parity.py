@@ -283,6 +283,13 @@ def test_tables_roundtrip_and_broadcast_equivalence(gpu_ctx):
     assert t.dtype == np.int32 and np.abs(t.astype(np.int64)).max() <= 1 << 28
     gpu_ctx.tables_import(t)
     assert np.array_equal(gpu_ctx.tables_export(), t)
+    # a table that is not the one the library derives from its own arc.bin / mds.bin is refused: it would
+    # bypass the Cauchy-structure and column-bound checks of p252_create and give silently wrong digests
+    bad = t.copy()
+    bad[100] ^= 1
+    with pytest.raises(ValueError):
+        gpu_ctx.tables_import(bad)
+    assert np.array_equal(gpu_ctx.tables_export(), t)  # the device table is untouched
 
 
 def test_adversarial_noncanonical_limbs_on_gpu(gpu_ctx, oracle_mod):

@@ -232,3 +232,24 @@ def test_dynamic_bounds(oracle_mod, hosttest_lib):
     assert top < 2 ** 27, math.log2(top)     # what max_column_bound29 assumes for the multiplicands of generic products
     assert top1 < 2 ** 30, math.log2(top1)   # W_0 = 28 X_4: enters one-digit products only (charged as 2 x 2^29 there)
     print("max |column| 2^%.2f, max |top digit| 2^%.2f (W_0: 2^%.2f)" % (math.log2(col), math.log2(top), math.log2(top1)))
+
+
+def test_digest_path_with_hoisted_tag_sbox(oracle_mod, hosttest_lib):
+    """k_merkle4's specialisation on the host: lane 0's first S-box precomputed from the tag (hades_pre0), last layer
+    reduced to the squeezed row — against Hash::digest(Merkle4, ..) of the oracle, random / edge / non-canonical tags"""
+    n = 500
+    x = oracle_mod.fill_random(1234, 4 * n).reshape(n, 4, 4)
+    tags = [oracle_mod.tag(0, [4], 1), oracle_mod.fill_random(5, 1)[0], np.zeros(4, dtype=np.uint64),
+            np.array(oracle_mod.int_to_limbs(P - 1), dtype=np.uint64)]
+    for tag in tags:
+        tag = np.ascontiguousarray(tag, dtype=np.uint64)
+        out = np.empty((n, 4), dtype=np.uint64)
+        hosttest_lib.ht_merkle4_digest29(p(tag), p(x), p(out), n)
+        assert np.array_equal(out, oracle_mod.hash_batch(tag, x, 4, 1).reshape(n, 4))
+    # a non-canonical tag pattern (the device reads 256 bits as an integer): same residue class as tag mod p
+    raw = np.array(oracle_mod.int_to_limbs((1 << 256) - 5), dtype=np.uint64)
+    red = np.array(oracle_mod.int_to_limbs(((1 << 256) - 5) % P), dtype=np.uint64)
+    a, b = np.empty((n, 4), dtype=np.uint64), np.empty((n, 4), dtype=np.uint64)
+    hosttest_lib.ht_merkle4_digest29(p(raw), p(x), p(a), n)
+    hosttest_lib.ht_merkle4_digest29(p(red), p(x), p(b), n)
+    assert np.array_equal(a, b)

@@ -30,7 +30,8 @@ FOUR_CYCLE_PREFIXES = ("v_mad_i64_i32", "v_mad_u64_u32", "v_lshl_add_u64", "v_as
                        "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_alignbit_b32", "v_add3_u32", "v_add_co_u32",
                        "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_lshl_or_b32", "v_and_or_b32", "v_bfe_u32", "v_bfe_i32",
                        "v_cmp_", "v_readlane", "v_writelane", "v_mad_u32_u24", "v_lshl_add_u32", "v_add_lshl_u32", "v_xad_u32",
-                       "v_perm_b32", "v_bfi_b32", "v_mov_b64", "v_pk_mov_b32")
+                       "v_perm_b32", "v_bfi_b32", "v_mov_b64", "v_pk_mov_b32", "v_lshlrev_b32", "v_mul_i32_i24", "v_mul_u32_u24",
+                       "v_fma_f64", "v_mov_b32_dpp")
 
 
 def compile_asm(extra_flags=()):
@@ -142,6 +143,26 @@ def simulate(prog, labels, args, max_steps=50_000_000):
     def signed(v):
         return v - (1 << 32) if v & 0x80000000 else v
 
+    vconst = {}     # vgpr index -> wave-uniform constant it holds (v_mov_b32 from an immediate / a known SGPR)
+
+    def vval(op):
+        op = op.strip()
+        m = re.fullmatch(r"v(\d+)", op)
+        if m:
+            return vconst.get(int(m.group(1)))
+        return sval(op)
+
+    def vkill(op):
+        op = op.strip()
+        m = re.fullmatch(r"v(\d+)", op)
+        if m:
+            vconst.pop(int(m.group(1)), None)
+        else:
+            m = re.fullmatch(r"v\[(\d+):(\d+)\]", op)
+            if m:
+                for k in range(int(m.group(1)), int(m.group(2)) + 1):
+                    vconst.pop(k, None)
+
     pc, steps = 0, 0
     while True:
         steps += 1
@@ -152,6 +173,16 @@ def simulate(prog, labels, args, max_steps=50_000_000):
         nxt = pc + 1
         if mn == "s_endpgm":
             break
+        if ops and (mn.startswith(("v_", "global_load", "buffer_load", "flat_load", "ds_read", "scratch_load"))):
+            src = None
+            if mn == "v_mov_b32_e32" and len(ops) == 2:
+                src = vval(ops[1])
+            elif mn in ("v_add_u32_e32", "v_add_u32") and len(ops) == 3:  # loop bound advanced on the vector unit
+                a, b = vval(ops[1]), vval(ops[2])
+                src = None if a is None or b is None else (a + b) & MASK32
+            vkill(ops[0])
+            if src is not None:
+                vconst[int(ops[0].strip()[1:])] = src
         if mn in ("s_mov_b32", "s_movk_i32"):
             v = sval(ops[1])
             if mn == "s_movk_i32" and v is not None:
@@ -219,8 +250,17 @@ def simulate(prog, labels, args, max_steps=50_000_000):
                     r = "exec" if a == 0xFFFFFFFFFFFFFFFF else (0 if a == 0 else None)
                 elif isinstance(a, int) and isinstance(b, int):
                     r = a & b
+            elif mn == "s_andn2_b64":
+                if a == "exec" and isinstance(b, int):
+                    r = "exec" if b == 0 else (0 if b == 0xFFFFFFFFFFFFFFFF else None)
+                elif isinstance(a, int) and isinstance(b, int):
+                    r = a & ~b & 0xFFFFFFFFFFFFFFFF
+            elif mn == "s_or_b64" and isinstance(a, int) and isinstance(b, int):
+                r = a | b
+            elif mn == "s_xor_b64" and isinstance(a, int) and isinstance(b, int):
+                r = a ^ b
             if ops[0].strip() == "vcc":
-                vccz = None if r is None else (r == 0)
+                vccz = None if r is None else (r == 0)  # ("exec" stands for a non-empty mask)
                 scc = None if r is None else int(r != 0)
             elif ops[0].strip() == "exec":
                 pass
@@ -270,7 +310,15 @@ def simulate(prog, labels, args, max_steps=50_000_000):
         elif mn == "v_readfirstlane_b32":
             setd(ops[0], None)
         elif mn.startswith("v_cmp") or mn.startswith("v_cmpx"):
+            # a loop bound the compiler parked in a VGPR (wave-uniform constant) compared on the vector unit
             vccz = None
+            m = re.fullmatch(r"v_cmp_(eq|ne|lg|gt|ge|lt|le)_(u32|i32)_e32", mn)
+            if m and ops[0].strip() == "vcc":
+                a, b = vval(ops[1]), vval(ops[2])
+                if a is not None and b is not None:
+                    x, y = (signed(a), signed(b)) if m.group(2) == "i32" else (a, b)
+                    res = {"eq": x == y, "ne": x != y, "lg": x != y, "gt": x > y, "ge": x >= y, "lt": x < y, "le": x <= y}[m.group(1)]
+                    vccz = not res
         pc = nxt
     return counts
 
