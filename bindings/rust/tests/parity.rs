@@ -1,15 +1,16 @@
-//! Run on a machine with an MI355X AND the dusk crates: this is the test that turns the tag from
-//! "parity unpinned" into pinned.  Shapes follow the reference's
-//! tests/hash.rs (3/5/15 inputs; (3,3), (5,2), (4,7) outputs) plus the Merkle domains and config 4.
+//! Run on a machine with an MI355X AND the dusk crates (RUN.md): this is the test that turns "parity unpinned" into
+//! pinned for (i) the tag and (ii) the encryption construction.
+//! Shapes follow the reference's tests/hash.rs (3 / 5 / 15 inputs; (3,3), (5,2), (4,7) outputs: tests/hash.rs:101-116,
+//! 188-203, 277-292) plus the Merkle domains and BASELINE config 4, and tests/encryption.rs (message_len 42 and 21).
 use dusk_bls12_381::BlsScalar;
 use dusk_poseidon::{Domain, Hash};
-use dusk_poseidon_hip::HashBatch;
+use dusk_poseidon_hip::{hash_tag, HashBatch};
 use ff::Field;
 use rand::rngs::StdRng;
 use rand::SeedableRng;
 
 #[test]
-fn gpu_matches_reference() {
+fn gpu_matches_reference_hash() {
     let mut rng = StdRng::seed_from_u64(0xbeef);
     for (domain, n_in, n_out) in [
         (Domain::Merkle4, 4, 1), (Domain::Merkle2, 2, 1), (Domain::Other, 3, 1), (Domain::Other, 5, 1),
@@ -22,7 +23,73 @@ fn gpu_matches_reference() {
             let mut h = Hash::new(domain);
             h.output_len(n_out);
             h.update(&input[i * n_in..(i + 1) * n_in]);
-            assert_eq!(h.finalize(), &got[i * n_out..(i + 1) * n_out]);
+            assert_eq!(h.finalize(), &got[i * n_out..(i + 1) * n_out], "{domain:?} {n_in}->{n_out} item {i}");
+        }
+    }
+}
+
+/// `Hash::update` chunks: the README example (README.md:31-44) hashes `[..3]` then `[3..]`; the digest must equal the
+/// one-chunk hash only if dusk-safe aggregates adjacent absorbs in the tag input — printed for the record.
+#[test]
+fn chunked_updates_and_the_tag_input_encoding() {
+    let (t1, log1) = hash_tag(Domain::Other, &[42], 1).unwrap();
+    let (t2, log2) = hash_tag(Domain::Other, &[3, 39], 1).unwrap();
+    println!("tag input [Absorb(42), Squeeze(1)]            = {:02x?}", log1.tag_input);
+    println!("tag input [Absorb(3), Absorb(39), Squeeze(1)] = {:02x?}", log2.tag_input);
+    assert_eq!(t1, t2, "dusk-safe aggregates adjacent absorb calls");
+    // the library's own helper (UNPINNED until this passes)
+    let lens = [42usize];
+    let mut lib_tag = [0u64; 4];
+    let rc = unsafe { dusk_poseidon_hip::sys::p252_tag(dusk_poseidon_hip::sys::P252_DOMAIN_OTHER, lens.as_ptr(), 1, 1, lib_tag.as_mut_ptr()) };
+    assert_eq!(rc, 0);
+    assert_eq!(t1.0, lib_tag, "p252_tag reproduces BlsScalar::hash_to_scalar over dusk-safe's tag input");
+}
+
+#[cfg(feature = "encryption")]
+mod encryption {
+    use super::*;
+    use dusk_jubjub::{JubJubAffine, JubJubScalar, GENERATOR_EXTENDED};
+    use dusk_poseidon::{decrypt, encrypt};
+    use dusk_poseidon_hip::sys::{P252_CRYPT_DUPLEX, P252_CRYPT_STREAM};
+    use dusk_poseidon_hip::{decrypt_batch, encrypt_batch, encryption_tag, Context};
+
+    /// Decides which of the library's two call sequences is dusk-safe's, at the message lengths of benches/encrypt.rs (2)
+    /// and tests/encryption.rs (21, 42): exactly the STREAM variant is expected to match for every length; for len <= 4
+    /// both do (they coincide there).
+    #[test]
+    fn gpu_matches_reference_encryption() {
+        let mut rng = StdRng::seed_from_u64(0x42424242);
+        let ctx = Context::new(0);
+        for len in [2usize, 21, 42] {
+            let (_, log) = encryption_tag(len).unwrap();
+            println!("dusk_safe::encrypt tag input for len {len}: {:02x?} ({} permutations)", log.tag_input, log.permutations);
+            let n = 64;
+            let mut msgs = Vec::new();
+            let mut secrets = Vec::new();
+            let mut nonces = Vec::new();
+            let mut expected = Vec::new();
+            for _ in 0..n {
+                let shared: JubJubAffine = (GENERATOR_EXTENDED * &JubJubScalar::random(&mut rng)).into();
+                let nonce = BlsScalar::random(&mut rng);
+                let m: Vec<BlsScalar> = (0..len).map(|_| BlsScalar::random(&mut rng)).collect();
+                expected.extend(encrypt(&m, &shared, &nonce).unwrap());
+                assert_eq!(decrypt(&expected[expected.len() - len - 1..], &shared, &nonce).unwrap(), m);
+                msgs.extend(m);
+                secrets.push([shared.get_u(), shared.get_v()]);
+                nonces.push(nonce);
+            }
+            let stream = encrypt_batch(&ctx, P252_CRYPT_STREAM, &msgs, len, &secrets, &nonces).unwrap();
+            let duplex = encrypt_batch(&ctx, P252_CRYPT_DUPLEX, &msgs, len, &secrets, &nonces).unwrap();
+            println!("len {len}: STREAM matches dusk-safe: {}, DUPLEX matches: {}", stream == expected, duplex == expected);
+            assert!(stream == expected || duplex == expected, "neither candidate is dusk-safe's construction");
+            let variant = if stream == expected { P252_CRYPT_STREAM } else { P252_CRYPT_DUPLEX };
+            let back = decrypt_batch(&ctx, variant, &expected, len, &secrets, &nonces).unwrap();
+            for (i, item) in back.into_iter().enumerate() {
+                assert_eq!(item.unwrap(), &msgs[i * len..(i + 1) * len]);
+            }
+            // tests/encryption.rs:60-115: a wrong nonce must fail on every item
+            let wrong: Vec<BlsScalar> = nonces.iter().map(|x| x + BlsScalar::one()).collect();
+            assert!(decrypt_batch(&ctx, variant, &expected, len, &secrets, &wrong).unwrap().iter().all(|r| r.is_err()));
         }
     }
 }

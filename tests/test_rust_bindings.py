@@ -1,0 +1,46 @@
+"""The Rust shim cannot be compiled here (no toolchain), so its FFI surface is kept honest mechanically:
+bindings/rust/src/sys.rs is generated from include/poseidon252_hip.h, must be up to date, and must declare exactly the
+symbols the shared library exports with the header's arity; lib.rs may only call functions sys.rs declares."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_sys_rs_is_in_sync_with_the_header():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py"), "--check"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+
+
+def test_every_header_function_is_declared_with_the_same_arity():
+    import gen_rust_sys as g
+    _, protos = g.parse_header()
+    text = open(g.SYS_RS).read()
+    rust = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (p252_\w+)\((.*?)\)", text)}
+    assert sorted(rust) == sorted(name for name, _, _ in protos) and len(rust) >= 35
+    for name, _, params in protos:
+        n_rust = 0 if not rust[name].strip() else rust[name].count(":")
+        assert n_rust == len(params), name
+    from poseidon252_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in rust:
+        assert hasattr(L, name), name
+    assert sorted(rust) == sorted(_lib.ABI_SYMBOLS)
+
+
+def test_lib_rs_calls_only_declared_functions_and_no_private_dusk_api():
+    lib = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    sysrs = open(os.path.join(ROOT, "bindings", "rust", "src", "sys.rs")).read()
+    declared = set(re.findall(r"pub fn (p252_\w+)", sysrs))
+    code = re.sub(r"//.*", "", lib)  # the doc comments mention p252_tag, which the shim deliberately never calls
+    used = set(re.findall(r"\b(p252_\w+)\s*\(", code))
+    assert used and used <= declared, used - declared
+    assert "tag_input(" not in code                        # dusk_safe::tag_input is crate-private
+    assert "impl Safe<BlsScalar, 5> for TagProbe" in lib    # the tag comes from a tag-capturing Safe (src/hades.rs:63-92 pattern)
+    parity = open(os.path.join(ROOT, "bindings", "rust", "tests", "parity.rs")).read()
+    for shape in ("(Domain::Other, 3, 3)", "(Domain::Other, 5, 2)", "(Domain::Other, 4, 7)", "[2usize, 21, 42]"):
+        assert shape in parity
