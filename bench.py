@@ -32,16 +32,42 @@ sys.path.insert(0, ROOT)
 
 # algorithmic figures
 MACS_PER_PERM_REFERENCE = 256_000      # 2000 field mults x 128 32x32->64 MACs (reference schedule)
-# v_mad_i64_i32 instructions one lane executes per Merkle4 digest with the integer-ARMA schedule:
-# 100 S-boxes x 387 + 60 x (153 G-product + 121 ARMA row) + 36 integer rows x 61 + entry 644 + exit 1,380 + F 153
-MACS_PER_PERM_EXECUTED = 59_513
 BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 12.0,
                   "openings": (32 + 12 * 96 + 12 + 32) / 12.0,  # leaf + 12 x 3 siblings + 12 position bytes + root
                   "encrypt": (5 * 32 + 3 * 32) / 2.0}             # 2 message + 2 secret + 1 nonce scalars in, 3 cipher scalars out
-# measured on MI355X by bench_tools/valu_rates.hip (profiles/r01_valu_rates_gfx950.txt):
-# v_mad_u64_u32 sustains 504.9 G wave-instructions/s chip-wide = 32.3e12 lane-MACs/s
-PEAK_INT32_MAC_PER_S = 504.9e9 * 64
+KERNEL_OF = {"merkle4_digests": "k_merkle4", "tree": "k_merkle4", "sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}
+# VALU issue peak of the chip (the binding roofline): a wave64 v_mad_i64_i32 occupies its SIMD for 4
+# cycles, so 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s = 39.3 T lane-MACs/s.  The clock is the one
+# GRBM_GUI_ACTIVE / duration shows during this very kernel (profiles/r02_pmc_k_merkle4.txt: 2.40 GHz).  For reference,
+# the best a pure dependent-free multiply-add stream was MEASURED to sustain after clock ramp is lower
+# (profiles/r02_valu_rates_gfx950.txt: 531 G/s at 4 waves per SIMD) — reported beside it, never used as the peak,
+# because a peak the kernel's own instruction mix can exceed is not a peak.
+SIMDS, NOMINAL_CLOCK_HZ = 1024, 2.4e9
+PEAK_WAVE_INST_4CYCLE_PER_S = SIMDS * NOMINAL_CLOCK_HZ / 4.0
+PEAK_INT32_MAC_PER_S = PEAK_WAVE_INST_4CYCLE_PER_S * 64
+MEASURED_MAD_STREAM_WAVE_INST_PER_S = 531.2e9
 PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def _latest(pattern):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return paths[-1] if paths else None
+
+
+def isa_counts(kernel):
+    """instructions one lane executes per pass of `kernel`, derived from the ISA of the committed sources by
+    tools/isa_count.py (scalar control flow interpreted, vector instructions counted; tests/test_isa_counts.py keeps the
+    file in step with the kernels).  k_sponge / k_merkle4_path / k_crypt run the same permutation body as k_permute
+    (all five lanes kept) once per permutation, so k_permute's figures stand for them."""
+    path = _latest("r*_isa_counts.json")
+    if not path:
+        return None
+    d = json.load(open(path))
+    key = kernel if kernel in d else "k_permute"
+    c = dict((k, v) for k, v in d[key].items() if k != "by_mnemonic")
+    c["source"] = os.path.relpath(path, ROOT) + ":" + key
+    return c
 
 
 def parse():
@@ -56,45 +82,41 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(workload, units_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-    command (FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected as
-    MI355X_MICROARCH.md §HBM prescribes: KB units, FETCH_SIZE doubled on gfx950) — bench.py cannot run the
-    profiler on itself, so the figure is read from profiles/ and scaled to this launch size; None if no
-    profile of this workload is committed."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_merkle4.json"))):
-        try:
-            d = json.load(open(path))
-            if "hbm_bytes_per_launch" in d:
-                best = (path, d)
-        except (OSError, ValueError):
-            continue
-    if best is None or workload != "merkle4_digests":
+def pmc_profile(kernel):
+    """the committed rocprofv3 --pmc summary of `kernel` from the latest round (tools/run_pmc.sh + tools/pmc_summary.py:
+    counters collected in separate passes; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled on gfx950 as
+    MI355X_MICROARCH.md §HBM prescribes) — bench.py cannot run the profiler on itself"""
+    path = _latest("r*_pmc_%s.json" % kernel)
+    if not path:
         return None
-    path, d = best
-    return {"bytes": d["hbm_bytes_per_launch"] * units_per_launch / d["units_per_launch"],
-            "algorithmic_bytes": 160.0 * units_per_launch, "source": os.path.relpath(path, ROOT)}
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    d["source"] = os.path.relpath(path, ROOT)
+    return d
 
 
-def pmc_valu(workload):
-    """VALU issue utilisation of the dominant kernel from the committed --pmc pass (SQ_INSTS_VALU,
-    GRBM_GUI_ACTIVE): instructions per SIMD-cycle, where a stream of 4-cycle-class instructions
-    (v_mad_i64_i32, 64-bit adds/shifts) saturates at 0.25."""
-    import glob
-    if workload != "merkle4_digests":
+def pmc_traffic(kernel, workload, units_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed --pmc passes, scaled to this launch size"""
+    d = pmc_profile(kernel)
+    if not d or "hbm_bytes_per_launch" not in d or workload == "tree":  # (a tree is 12 launches of different sizes)
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_merkle4.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-            c = d["counters"]
-            per_simd_cycle = c["SQ_INSTS_VALU"] / (1024.0 * d["gpu_cycles_per_launch"])
-            return {"valu_insts_per_permutation": d["valu_insts_per_wave"] / 64.0, "valu_insts_per_simd_cycle": per_simd_cycle,
-                    "saturation_for_4cycle_class": 0.25, "source": os.path.relpath(path, ROOT)}
-        except (OSError, ValueError, KeyError):
-            continue
-    return None
+    scale = units_per_launch / d["units_per_launch"]
+    return {"bytes": d["hbm_bytes_per_launch"] * scale, "algorithmic_bytes": BYTES_PER_PERM[workload] * units_per_launch,
+            "ratio": d["hbm_bytes_per_launch"] * scale / (BYTES_PER_PERM[workload] * units_per_launch), "source": d["source"]}
+
+
+def pmc_valu(kernel):
+    """what the counters say about the same kernel: VALU instructions per wave (must equal the ISA-derived count) and
+    the clock during the kernel (GRBM_GUI_ACTIVE / 8 XCDs / duration)"""
+    d = pmc_profile(kernel)
+    if not d or "valu_insts_per_wave" not in d:
+        return None
+    out = {"valu_insts_per_wave": d["valu_insts_per_wave"], "source": d["source"]}
+    if d.get("gpu_cycles_per_launch") and d.get("avg_duration_us"):
+        out["clock_ghz"] = d["gpu_cycles_per_launch"] / (d["avg_duration_us"] * 1e3)
+    return out
 
 
 def usable_cpus():
@@ -421,6 +443,34 @@ def main():
         per_gpu_rate = perms_per_step / (k_ms * 1e-3)
         achieved_mac = per_gpu_rate * MACS_PER_PERM_REFERENCE
         hbm_gbps = per_gpu_rate * BYTES_PER_PERM[wl] / 1e9
+        kern = KERNEL_OF[wl]
+        isa = isa_counts(kern)
+        executed = issue = None
+        if isa:
+            mac_rate = per_gpu_rate * isa["v_mad_i64_i32"]
+            executed = {"macs_per_perm": isa["v_mad_i64_i32"], "achieved": mac_rate / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12,
+                        "frac": mac_rate / PEAK_INT32_MAC_PER_S, "unit": "TMAC/s", "source": isa["source"],
+                        "frac_of_measured_mad_stream": mac_rate / (MEASURED_MAD_STREAM_WAVE_INST_PER_S * 64),
+                        "note": "the fraction of the hardware: multiply-adds actually issued (counted in the ISA) / (1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes)"}
+            # every VALU instruction priced at its issue cost (4 cycles for multiply-adds, 64-bit adds / shifts and VOP3
+            # 3-operand forms, 2 for plain 32-bit ops — profiles/r02_valu_rates_gfx950.txt): share of all SIMD cycles
+            cyc = per_gpu_rate / 64.0 * isa["valu_issue_cycles"]
+            issue = {"valu_insts_per_perm": isa["valu_total"], "issue_cycles_per_perm": isa["valu_issue_cycles"],
+                     "frac": cyc / (SIMDS * NOMINAL_CLOCK_HZ), "pmc": pmc_valu(kern),
+                     "note": "SIMD cycles spent issuing VALU work under the 4-/2-cycle model / all SIMD cycles at 2.4 GHz"}
+        roofline = {
+            "bound": "valu-int32-mac", "kernel": kern,
+            "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
+            "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
+            "note": "SURVEY §8d figure: 256,000 MACs per permutation (reference schedule) x permutations per launch / mean launch time "
+                    "(HIP events on the launch stream) against the VALU issue peak.  The kernel runs an algebraically equivalent schedule with "
+                    "4x fewer multiply-adds, so this exceeds 1 and says nothing about the hardware; `executed.frac` does.",
+            "executed": executed, "valu_issue": issue,
+            "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
+            "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
+                    "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
+            "traffic": pmc_traffic(kern, wl, perms_per_step),
+        }
         line = {
             "metric": "Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact",
             "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -432,25 +482,10 @@ def main():
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input": "splitmix64 seed 0xc10d + rank, uniform mod p (SURVEY §8d)",
                        "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
-            "roofline": {
-                "bound": "valu-int32-mac", "kernel": {"sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}.get(wl, "k_merkle4"),
-                "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
-                "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
-                "note": "algorithmic MACs = 256,000 per permutation (reference schedule, SURVEY §8d) x permutations per launch / mean launch time "
-                        "(HIP events on the launch stream); peak = measured v_mad_u64_u32 issue rate (profiles/r01_valu_rates_gfx950.txt). "
-                        "The kernel executes an algebraically equivalent schedule with 4x fewer MACs (integer MDS + integer ARMA recurrence), "
-                        "so frac exceeds 1; 'executed' prices the MACs actually issued, 'valu_issue' the issue slots actually used.",
-                "executed": {"macs_per_perm": MACS_PER_PERM_EXECUTED, "achieved": per_gpu_rate * MACS_PER_PERM_EXECUTED / 1e12,
-                             "frac": per_gpu_rate * MACS_PER_PERM_EXECUTED / PEAK_INT32_MAC_PER_S} if wl == "merkle4_digests" else None,
-                "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
-                "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
-                        "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
-                "traffic": pmc_traffic(wl, perms_per_step),
-                "valu_issue": pmc_valu(wl),
-            },
+            "roofline": roofline,
             # the same kernel priced against the HBM roofline in the contract's shape (NOT the binding bound here)
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": hbm_gbps / PEAK_HBM_GBPS, "traffic": pmc_traffic(wl, perms_per_step)},
+                             "frac": hbm_gbps / PEAK_HBM_GBPS, "traffic": roofline["traffic"]},
             "self_consistency_ok": self_ok,
             "setup": {"wake_up_launches": WAKE_UP_LAUNCHES,
                       "note": "untimed launches of the same step before the W warm-up steps: brings an idle GPU's clocks to steady state"},

@@ -167,9 +167,11 @@ struct Entry {
 };
 
 int main(int argc, char** argv) {
-    bool with_latency = false;
-    for (int i = 1; i < argc; ++i)
+    bool with_latency = false, clock_mode = false;
+    for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--latency")) with_latency = true;
+        if (!strcmp(argv[i], "--clock")) clock_mode = true;  // short run for `rocprofv3 --pmc GRBM_GUI_ACTIVE`: few, long launches
+    }
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -217,11 +219,26 @@ int main(int argc, char** argv) {
         return launches;
     };
     ramp(300.0);
+    if (clock_mode) {
+        // 4 streams x 12 launches of ~2.5 ms at 4 waves/SIMD, back to back after the ramp: GRBM_GUI_ACTIVE / 8 / duration of
+        // each dispatch in the profiler's CSV is the shader clock this instruction mix runs at
+        struct { const char* name; void (*kern)(unsigned*, unsigned, int); } sel[] = {
+            {"v_mad_i64_i32 (sgpr)", k_mad_i64_i32_s}, {"v_and_b32", k_and_b32},
+            {"mix: wide step", k_mix_step_wide}, {"mix: tight step", k_mix_step_tight}};
+        for (auto& t : sel) {
+            for (int i = 0; i < 12; ++i) hipLaunchKernelGGL(t.kern, dim3(cus * 4), dim3(256), 0, 0, sink, 12345679u, 40000);
+            CHECK(hipDeviceSynchronize());
+            printf("clock mode: 12 launches of %s\n", t.name);
+        }
+        return 0;
+    }
     const double nominal_simd_cycles = 1024.0 * 2.4e9;
     printf("%-44s %6s %14s %16s %18s\n", "instruction", "w/SIMD", "Gwave-inst/s", "inst/SIMD-cycle", "cycles/inst/SIMD");
     for (auto& t : tests) {
-        for (int k : {1, 2, 4}) {
+        const bool is_mad = strstr(t.name, "v_mad_i64_i32 (sgpr)") || strstr(t.name, "mix:");
+        for (int k : {1, 2, 3, 4, 6, 8}) {
             if (t.latency && k != 1) continue;
+            if (!is_mad && (k == 3 || k == 6 || k == 8)) continue;  // the occupancy sweep only where it matters
             const int grid = cus * k;  // 256 threads = 4 waves = one wave per SIMD per block
             ramp(40.0);
             // >= 100 ms of back-to-back launches

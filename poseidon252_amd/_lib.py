@@ -51,6 +51,26 @@ def lib():
             "%s not found: build it with `python -m poseidon252_amd.build` "
             "(hipcc --offload-arch=gfx950).  poseidon252_amd has no CPU fallback." % LIB_PATH)
     L = ctypes.CDLL(LIB_PATH)
+    if os.environ.get("P252_LIB_PATH"):
+        # developer A/B switch only: an OLDER build of the library may lack entry points added since; give those a stub
+        # that fails loudly when called, so that the benchmarks of the entry points it does have can still be compared
+        class _Tolerant:
+            def __init__(self, lib):
+                self.__dict__["_l"] = lib
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._l, name)
+                except AttributeError:
+                    class _Missing:
+                        argtypes = restype = None
+
+                        def __call__(self, *a):
+                            raise ExtensionMissing("%s is not exported by %s" % (name, LIB_PATH))
+                    m = _Missing()
+                    self.__dict__[name] = m
+                    return m
+        L = _Tolerant(L)
     L.p252_device_count.restype = ctypes.c_int
     L.p252_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
     L.p252_destroy.argtypes = [_vp]

@@ -152,3 +152,54 @@ def test_two_contexts_and_streams(gpu_ctx, oracle_mod):
     s.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64).reshape(5000, 1, 4), exp)
     ctx2.close()
+
+
+def test_config5_per_gpu_share_2pow24_leaves_all_levels(gpu_ctx, oracle_mod):
+    """BASELINE configs[4] = 8 x this: ONE GPU's full share of the 2^27-leaf sharded tree — 2^24 leaves (512 MiB), ALL
+    levels written (5,592,405 nodes, 171 MiB) — generated on the device exactly as bench.py's rank 3 generates it
+    (SURVEY §8d generator, seed 0xc10d + rank).  Every one of the 12 levels is checked against the oracle on a random
+    sample of nodes (each node = Hash::digest(Merkle4, its 4 children in the level below)), the top 3 levels in full;
+    then the 8-way composition of configs[4]: roots of 8 such-shaped subtrees (of 4^6 leaves, to stay short) -> 2 -> 1
+    through the multi-context ABI equals the tree over the concatenation."""
+    import torch
+    import poseidon252_amd as P
+    from poseidon252_amd import multi, synth
+    n = 1 << 24
+    tag = P.merkle4_tag()
+    d = synth.splitmix_scalars(0xC10D + 3, n, "cuda")
+    assert np.array_equal(d[:1000].cpu().numpy().view(np.uint64), oracle_mod.fill_random(0xC10D + 3, 1000))  # the bytes bench.py times
+    total = P.levels_len(n)
+    assert total == 5592405
+    d_levels = torch.empty((total, 4), dtype=torch.int64, device="cuda")
+    d_root = torch.empty(4, dtype=torch.int64, device="cuda")
+    gpu_ctx.merkle4_tree_device(tag, d, n, d_root, d_levels)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    below, off, cnt = d, 0, n // 4
+    while cnt >= 1:
+        cur = d_levels[off:off + cnt]
+        idx = np.unique(rng.integers(0, cnt, size=min(cnt, 96))) if cnt > 64 else np.arange(cnt)
+        t_idx = torch.from_numpy(idx).cuda()
+        children = below.view(-1, 4, 4)[t_idx].cpu().numpy().view(np.uint64)
+        exp = oracle_mod.hash_batch(tag, children, 4, 1).reshape(-1, 4)
+        assert np.array_equal(cur[t_idx].cpu().numpy().view(np.uint64), exp), "level with %d nodes" % cnt
+        below, off, cnt = cur, off + cnt, cnt // 4
+    assert off == total and torch.equal(d_root, d_levels[-1])
+    # root-only build (ping-pong scratch, what bench.py --workload tree times) gives the same root
+    d_root2 = torch.empty(4, dtype=torch.int64, device="cuda")
+    gpu_ctx.merkle4_tree_device(tag, d, n, d_root2, None)
+    torch.cuda.synchronize()
+    assert torch.equal(d_root, d_root2)
+    # configs[4] composition at 8 shards: gather of 8 roots, then [r0..r3], [r4..r7] -> 2 nodes -> [n0, n1, 0, 0] -> root
+    per = 4 ** 6
+    sub = d[:8 * per].cpu().numpy().view(np.uint64)
+    ctxs = [P.Context(0) for _ in range(8)]
+    root8 = multi.merkle4_tree_multi(ctxs, tag, sub)
+    for c in ctxs:
+        c.close()
+    assert np.array_equal(root8, oracle_mod.merkle4_tree(tag, sub)[0])
+    roots = np.stack([P.merkle4_tree(sub[i * per:(i + 1) * per], tag=tag, ctx=gpu_ctx) for i in range(8)])
+    zero = np.zeros((2, 4), dtype=np.uint64)
+    n01 = oracle_mod.hash_batch(tag, roots.reshape(2, 4, 4), 4, 1).reshape(2, 4)
+    top = oracle_mod.hash_batch(tag, np.concatenate([n01, zero]).reshape(1, 4, 4), 4, 1).reshape(4)
+    assert np.array_equal(root8, top)  # 8 subtrees + 3 top permutations: 44,739,243 in all at full size (SURVEY §8a)

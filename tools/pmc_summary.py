@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV passes (gpurun_out/pmc_*/pmc_counter_collection.csv) for one kernel.
-usage: pmc_summary.py <kernel-substring> <units_per_launch> <dir> [<dir> ...]   -> text on stdout, JSON on fd 3 if open"""
+usage: pmc_summary.py <kernel-substring> <units_per_launch> [--bytes-per-unit B] <dir> [<dir> ...]
+-> text on stdout, JSON on fd 3 if open.  units = permutations per launch; B = algorithmic bytes per permutation."""
 import collections
 import csv
 import json
@@ -10,21 +11,34 @@ import sys
 
 def main():
     kern, units = sys.argv[1], float(sys.argv[2])
+    rest = sys.argv[3:]
+    bpu = 160.0
+    if rest and rest[0] == "--bytes-per-unit":
+        bpu = float(rest[1])
+        rest = rest[2:]
     agg = collections.defaultdict(list)
+    durs = []
     rows = []
-    for d in sys.argv[3:]:
+    for d in rest:
         rows += [r for r in csv.DictReader(open(os.path.join(d, "pmc_counter_collection.csv"))) if kern in r["Kernel_Name"]]
     full = max(int(r["Grid_Size"]) for r in rows)  # the timed launches; smaller self-check launches of the same kernel are left out
     for r in rows:
         if int(r["Grid_Size"]) == full:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                durs.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
             meta = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
     avg = {k: sum(v) / len(v) for k, v in agg.items()}
     print("# rocprofv3 --pmc summary for kernel *%s* (avg per dispatch over %d dispatches, separate passes per counter group)" % (kern, len(next(iter(agg.values())))))
     print("# grid=%s wg=%s vgpr=%s sgpr=%s scratch=%s lds=%s ; units (permutations) per launch = %d" % (meta + (units,)))
     for k in sorted(avg):
         print("%-24s %.6g" % (k, avg[k]))
-    out = {"kernel": kern, "units_per_launch": units, "counters": avg}
+    out = {"kernel": kern, "units_per_launch": units, "counters": avg, "algorithmic_bytes_per_unit": bpu}
+    if durs:
+        durs.sort()
+        out["avg_duration_us"] = sum(durs) / len(durs)
+        out["median_duration_us"] = durs[len(durs) // 2]
+        print("%-24s %.6g   (median %.6g; under counter collection, dispatches are serialised)" % ("avg_duration_us", out["avg_duration_us"], out["median_duration_us"]))
     if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
         # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly half
         # of the bytes of a wide (16 B/lane) streaming read -> doubled; WRITE_SIZE taken as is (it equals the
@@ -34,8 +48,9 @@ def main():
         out["hbm_bytes_per_launch"] = rd + wr
         print("hbm_read_bytes (2 x FETCH_SIZE KB)   %.6g" % rd)
         print("hbm_write_bytes (WRITE_SIZE KB)      %.6g" % wr)
-        print("hbm_bytes_per_launch                 %.6g   (algorithmic: %.6g = 160 B x units)" % (rd + wr, 160.0 * units))
-        print("traffic / algorithmic                %.3f" % ((rd + wr) / (160.0 * units)))
+        print("hbm_bytes_per_launch                 %.6g   (algorithmic: %.6g = %.4g B x units)" % (rd + wr, bpu * units, bpu))
+        print("traffic / algorithmic                %.3f" % ((rd + wr) / (bpu * units)))
+        out["traffic_ratio"] = (rd + wr) / (bpu * units)
     if "SQ_INSTS_VALU" in avg and "SQ_WAVES" in avg:
         per_wave = avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]
         out["valu_insts_per_wave"] = per_wave
@@ -44,6 +59,9 @@ def main():
             cyc = avg["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
             out["gpu_cycles_per_launch"] = cyc
             print("GPU cycles per launch (GRBM_GUI_ACTIVE / 8 XCDs)     %.4g" % cyc)
+            if durs:
+                print("shader clock during the kernel (cycles / median duration)   %.3f GHz" % (cyc / (out["median_duration_us"] * 1e3)))
+                out["clock_ghz"] = cyc / (out["median_duration_us"] * 1e3)
             print("VALU instructions per SIMD-cycle (1024 SIMDs)        %.3f   (a 4-cycle-class stream saturates at 0.25, 2-cycle at 0.5)" % (avg["SQ_INSTS_VALU"] / (1024.0 * cyc)))
     try:
         os.write(3, json.dumps(out).encode())
