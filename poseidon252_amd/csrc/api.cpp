@@ -413,7 +413,11 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
         const char* e = std::getenv("P252_HOST_PIPELINE");
         return e ? std::atoi(e) : 2;
     }();
-    const size_t chunk_bytes_target = (size_t)16 << 20;
+    static const size_t chunk_bytes_target = [] {  // P252_HOST_CHUNK_MB (developer switch): staging / DMA chunk size
+        const char* e = std::getenv("P252_HOST_CHUNK_MB");
+        const int mb = e ? std::atoi(e) : 16;
+        return (size_t)(mb < 1 ? 1 : (mb > 256 ? 256 : mb)) << 20;
+    }();
     size_t chunk = chunk_bytes_target / ((in_len > out_len ? in_len : out_len) * 32);
     if (chunk < 4096) chunk = 4096;
     chunk &= ~(size_t)255;
