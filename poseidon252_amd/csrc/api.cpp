@@ -321,10 +321,29 @@ static bool is_pinned(const void* p) {
 // The host copies of one lane overlap the DMA and kernels of the others; nothing the caller owns is ever registered.
 static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
                              uint64_t* out, size_t n, size_t chunk) {
+    // Lane count: the copies are CPU work, so it follows the CPU time this process may use (affinity mask and cgroup
+    // quota) — 3/4 of it, between 2 and 12.  Measured on the benchmark box (256 logical CPUs, quota 16): 12 lanes 3.1e8
+    // digests/s, 16 and more lanes 2.1e8 (the quota throttles the threads) — profiles/r02_host_path.txt.
+    // P252_HOST_LANES overrides.
     static const int lanes_wanted = [] {
-        const char* e = std::getenv("P252_HOST_LANES");
-        int v = e ? std::atoi(e) : 8;
-        return v < 1 ? 1 : (v > 32 ? 32 : v);
+        if (const char* e = std::getenv("P252_HOST_LANES")) {
+            const int v = std::atoi(e);
+            return v < 1 ? 1 : (v > 32 ? 32 : v);
+        }
+        double cpus = (double)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = (double)CPU_COUNT(&set);
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[32];
+            double period = 0;
+            if (std::fscanf(f, "%31s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+                const double quota = std::atof(q) / period;
+                if (quota > 0 && quota < cpus) cpus = quota;
+            }
+            std::fclose(f);
+        }
+        const int v = (int)(cpus * 0.75);
+        return v < 2 ? 2 : (v > 12 ? 12 : v);
     }();
     const size_t n_chunks = (n + chunk - 1) / chunk;
     const int n_lanes = (int)(n_chunks < (size_t)lanes_wanted ? n_chunks : (size_t)lanes_wanted);

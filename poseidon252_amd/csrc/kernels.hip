@@ -55,11 +55,14 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restric
 
 // ---- Merkle4 digest: Hash::digest(Domain::Merkle4, [c0..c3]) = perm([tag, c0, c1, c2, c3])[1]
 // (hash.rs:128-155 with io-pattern [Absorb(4), Squeeze(1)]).  `n_children` may be short of 4*n:
-// missing children are the zero scalar (hash.rs:22-26). ----
-__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4(const int32_t* __restrict__ tab, TagArg tag,
-                                                        const Scalar32* __restrict__ children,
-                                                        size_t n_children, Scalar32* __restrict__ out,
-                                                        size_t n, unsigned arity) {
+// missing children are the zero scalar (hash.rs:22-26).
+// Two builds of the same body: k_merkle4 (3 waves per SIMD: what a full machine wants, +1.2 % on 2^20 digests) and
+// k_merkle4_lat for launches of at most one wave per SIMD — a tree's narrow levels, small batches — where occupancy
+// is irrelevant and the unconstrained register allocation's schedule runs a lone wave 3.6 % faster (same-box A/B,
+// profiles/r02_ab_occupancy.txt). ----
+__device__ __forceinline__ void merkle4_body(const int32_t* __restrict__ tab, const TagArg& tag,
+                                             const Scalar32* __restrict__ children, size_t n_children,
+                                             Scalar32* __restrict__ out, size_t n, unsigned arity) {
     // arity 4: Domain::Merkle4 node; arity 2: Domain::Merkle2 node (hash.rs:27-31) — the same sponge with two
     // absorbed elements, i.e. state [tag, c0, c1, 0, 0]; the caller passes the matching tag
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
@@ -77,6 +80,18 @@ __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4(const in
     }
     hades_permute<0x02u, true>(s, tab);  // only lane 1 is squeezed
     store_scalar(out + idx, s[1]);
+}
+__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4(const int32_t* __restrict__ tab, TagArg tag,
+                                                        const Scalar32* __restrict__ children,
+                                                        size_t n_children, Scalar32* __restrict__ out,
+                                                        size_t n, unsigned arity) {
+    merkle4_body(tab, tag, children, n_children, out, n, arity);
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_lat(const int32_t* __restrict__ tab, TagArg tag,
+                                                            const Scalar32* __restrict__ children,
+                                                            size_t n_children, Scalar32* __restrict__ out,
+                                                            size_t n, unsigned arity) {
+    merkle4_body(tab, tag, children, n_children, out, n, arity);
 }
 
 // ---- generic sponge: n messages, same (in_len, out_len).  dusk-safe mechanics:
@@ -284,8 +299,13 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
                           void* out, size_t n, hipStream_t st, unsigned arity) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merkle4, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
-                       static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity);
+    // <= one wave per SIMD on the whole chip (256 CUs x 4 SIMDs x 64 lanes): the latency build
+    if (n <= (size_t)65536)
+        hipLaunchKernelGGL(k_merkle4_lat, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity);
+    else
+        hipLaunchKernelGGL(k_merkle4, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity);
     return hipGetLastError();
 }
 
