@@ -114,8 +114,8 @@ def pmc_valu(kernel):
     if not d or "valu_insts_per_wave" not in d:
         return None
     out = {"valu_insts_per_wave": d["valu_insts_per_wave"], "source": d["source"]}
-    if d.get("gpu_cycles_per_launch") and d.get("avg_duration_us"):
-        out["clock_ghz"] = d["gpu_cycles_per_launch"] / (d["avg_duration_us"] * 1e3)
+    if d.get("clock_ghz"):
+        out["clock_ghz"] = d["clock_ghz"]  # GRBM_GUI_ACTIVE / 8 XCDs / median dispatch duration of the same pass
     return out
 
 

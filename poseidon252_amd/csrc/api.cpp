@@ -263,11 +263,21 @@ static int merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[
         rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], l2 * 32);
         if (rc) return rc;
     }
+    // A build with wide levels (more nodes than the chip has lanes at one wave per SIMD: 65,536) keeps every SIMD
+    // loaded through its narrow levels by computing them redundantly (kernels.hip k_merkle4_pad: the next wide launch
+    // would otherwise start at a dipped clock).  P252_TREE_PAD_LANES overrides the lane count; 0 = off.
+    static const long pad_env = [] {
+        const char* e = std::getenv("P252_TREE_PAD_LANES");
+        return e ? std::atol(e) : -1L;
+    }();
+    const size_t chip_lanes = 65536;
+    const size_t first_level = (n_leaves + arity - 1) / arity;
+    const size_t pad = pad_env >= 0 ? (size_t)pad_env : (first_level > chip_lanes ? chip_lanes : 0);
     int parity = 0;
     while (cur_n > 1) {  // a single leaf is its own root: an arity^k-leaf tree costs exactly k levels
         const size_t next_n = (cur_n + arity - 1) / arity;
         char* next = d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]);
-        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, arity));
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, arity, pad));
         cur = next;
         cur_n = next_n;
         if (d_levels) lv += next_n * 32;

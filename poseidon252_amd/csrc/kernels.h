@@ -19,8 +19,9 @@ struct TagArg {
 };
 
 hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t n, hipStream_t st);
+// pad_lanes > n: the n nodes are computed redundantly by pad_lanes lanes (k_merkle4_pad: narrow levels of a large tree)
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
-                          void* out, size_t n, hipStream_t st, unsigned arity = 4);
+                          void* out, size_t n, hipStream_t st, unsigned arity = 4, size_t pad_lanes = 0);
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
                          unsigned out_len, void* out, size_t n, hipStream_t st);
 

@@ -93,6 +93,34 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_lat(const int32_t* __res
                                                             size_t n, unsigned arity) {
     merkle4_body(tab, tag, children, n_children, out, n, arity);
 }
+// The narrow levels of a LARGE tree, computed redundantly by `lanes` > n lanes (lane i hashes node i mod n; duplicates
+// store identical bytes): one wave on every SIMD of the chip instead of a handful of busy CUs.  Why: after ~1.4 ms of a
+// nearly idle chip (eight latency-bound levels) the next wide launch runs at a dipped shader clock — GRBM_GUI_ACTIVE
+// shows 2.14-2.25 GHz for a tree's 4M-node level against 2.36-2.40 GHz for the same kernel in a steady stream
+// (profiles/r02_bench_kernel_trace_tree.txt).  Holding the load level through the narrow phase costs those levels
+// nothing (they are bound by one wave's latency either way: 171 vs 174 us) and takes 3 % off a 2^24-leaf build in
+// steady state (same-box A/B, profiles/r02_ab_tree_pad.txt).  Results are bit-identical; P252_TREE_PAD_LANES=0 turns it off.
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_pad(const int32_t* __restrict__ tab, TagArg tag,
+                                                            const Scalar32* __restrict__ children,
+                                                            size_t n_children, Scalar32* __restrict__ out,
+                                                            size_t n, unsigned arity, size_t lanes) {
+    const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (lane >= lanes) return;
+    const size_t idx = lane % n;
+    E29 s[WIDTH];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) s[0].d[k] = tag.x0[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t c = idx * arity + k;
+        if ((unsigned)k < arity && c < n_children)
+            s[1 + k] = load_scalar(children + c);
+        else
+            s[1 + k] = e29_zero();
+    }
+    hades_permute<0x02u, true>(s, tab);
+    store_scalar(out + idx, s[1]);
+}
 
 // ---- generic sponge: n messages, same (in_len, out_len).  dusk-safe mechanics:
 // absorb 4 elements per permutation into state[1..4]; first squeeze always permutes; 4 outputs per
@@ -297,8 +325,13 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 }
 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
-                          void* out, size_t n, hipStream_t st, unsigned arity) {
+                          void* out, size_t n, hipStream_t st, unsigned arity, size_t pad_lanes) {
     if (n == 0) return hipSuccess;
+    if (n < pad_lanes) {
+        hipLaunchKernelGGL(k_merkle4_pad, dim3(grid_for(pad_lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, pad_lanes);
+        return hipGetLastError();
+    }
     // <= one wave per SIMD on the whole chip (256 CUs x 4 SIMDs x 64 lanes): the latency build
     if (n <= (size_t)65536)
         hipLaunchKernelGGL(k_merkle4_lat, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,

@@ -312,3 +312,25 @@ def test_adversarial_noncanonical_limbs_on_gpu(gpu_ctx, oracle_mod):
     got = gpu_ctx.hash_batch(st[0, 1], msg[None], 9, 6)[0]
     exp = pymodel.sponge(states[0][1] * Rinv % P, [s[0] * Rinv % P for s in states[:9]], 6, perm=lambda x: pymodel.perm_reference(x, C, M))
     assert [oracle_mod.int_from_mont(x) for x in got] == exp
+
+
+def test_tree_with_padded_narrow_levels_is_bit_identical(gpu_ctx, oracle_mod):
+    """the narrow levels of a large tree are computed redundantly on every SIMD (k_merkle4_pad: lane i hashes node
+    i mod n) to hold the chip's power state; forced on for SMALL trees here (P252_TREE_PAD_LANES is read once per
+    process, hence the subprocess): roots and all levels equal the un-padded build and the oracle, arity 4 and 2"""
+    import subprocess, sys
+    code = r'''
+import numpy as np, oracle, poseidon252_amd as P
+ctx = P.Context(0)
+tag = P.merkle4_tag()
+for n in (1, 2, 5, 64, 1000, 4096, 70000):
+    lv = oracle.fill_random(900 + n, n)
+    root, levels = P.merkle4_tree(lv, tag=tag, ctx=ctx, want_levels=True)
+    o_root, o_levels = oracle.merkle4_tree(tag, lv)
+    assert np.array_equal(root, o_root) and np.array_equal(np.asarray(levels).reshape(-1, 4), np.asarray(o_levels).reshape(-1, 4)), n
+print("PAD OK")
+'''
+    import os
+    env = dict(os.environ, P252_TREE_PAD_LANES="16384")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(HERE), env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0 and b"PAD OK" in out.stdout, out.stdout.decode() + out.stderr.decode()
