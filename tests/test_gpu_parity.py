@@ -317,7 +317,7 @@ def test_adversarial_noncanonical_limbs_on_gpu(gpu_ctx, oracle_mod):
 def test_tree_with_padded_narrow_levels_is_bit_identical(gpu_ctx, oracle_mod):
     """the narrow levels of a large tree are computed redundantly on every SIMD (k_merkle4_pad: lane i hashes node
     i mod n) to hold the chip's power state; forced on for SMALL trees here (P252_TREE_PAD_LANES is read once per
-    process, hence the subprocess): roots and all levels equal the un-padded build and the oracle, arity 4 and 2"""
+    process, hence the subprocess): roots and all levels equal the oracle's, arity 4 and 2"""
     import subprocess, sys
     code = r'''
 import numpy as np, oracle, poseidon252_amd as P
@@ -326,8 +326,12 @@ tag = P.merkle4_tag()
 for n in (1, 2, 5, 64, 1000, 4096, 70000):
     lv = oracle.fill_random(900 + n, n)
     root, levels = P.merkle4_tree(lv, tag=tag, ctx=ctx, want_levels=True)
-    o_root, o_levels = oracle.merkle4_tree(tag, lv)
-    assert np.array_equal(root, o_root) and np.array_equal(np.asarray(levels).reshape(-1, 4), np.asarray(o_levels).reshape(-1, 4)), n
+    o_root, o_levels, _ = oracle.merkle4_tree(tag, lv, want_levels=True)
+    assert np.array_equal(root, o_root) and np.array_equal(levels, o_levels), n
+    tag2 = oracle.tag(1, [2], 1)
+    root2, levels2 = ctx.merkle2_tree(tag2, lv[:min(n, 3000)], want_levels=True)
+    o2 = oracle.merkle2_tree(tag2, lv[:min(n, 3000)], want_levels=True)
+    assert np.array_equal(root2, o2[0]) and np.array_equal(levels2, o2[1]), n
 print("PAD OK")
 '''
     import os
