@@ -2,7 +2,7 @@
 # pageable host->host rate of p252_hash_batch (2^22 Merkle4 digests) for several staging-lane counts and chunk sizes
 # (P252_HOST_LANES / P252_HOST_CHUNK_MB are read once per process, hence one process per point)
 cd "$(dirname "$0")/.."
-for chunk in 4 16; do for lanes in 4 8 12 16 24 32; do
+for chunk in 4 8 16; do for lanes in 2 3 4 6 8 12; do
 P252_HOST_LANES=$lanes P252_HOST_CHUNK_MB=$chunk python - <<PY
 import time, numpy as np, poseidon252_amd as P
 ctx = P.Context(0); hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)

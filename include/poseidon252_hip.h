@@ -96,9 +96,10 @@ size_t p252_merkle2_levels_len(size_t n_leaves);
 
 /* Page-locked host memory (hipHostMalloc).  p252_hash_batch pipelines H2D / kernel / D2H for large batches.  With
  * ordinary (pageable) caller memory — a Rust Vec<BlsScalar> — nothing the caller owns is touched: chunks go through
- * library-owned page-locked staging lanes (one worker thread, stream and buffer pair per lane; P252_HOST_LANES, default
- * 8) so that the host copies of one lane overlap the DMA and kernels of the others.  With buffers from p252_host_alloc /
- * p252_host_register on BOTH sides the copies are zero-copy DMA over 3 streams.  NULL on failure. */
+ * library-owned page-locked staging lanes (a worker thread and stream per lane, two chunks in flight per lane;
+ * P252_HOST_LANES, default 3; P252_HOST_CHUNK_MB, default 8) so that the host copy of one chunk overlaps the DMA and kernel
+ * of the others: 3.5-3.8e8 Merkle4 digests/s host-to-host.  With buffers from p252_host_alloc / p252_host_register on BOTH
+ * sides the copies are zero-copy DMA over 3 streams: 4.0e8.  NULL on failure. */
 void* p252_host_alloc(size_t bytes);
 void p252_host_free(void* p);
 /* Page-lock / release a buffer the caller already owns (hipHostRegister / hipHostUnregister) — e.g. a Rust

@@ -36,13 +36,17 @@ struct p252_ctx {
     hipStream_t streams[3] = {nullptr, nullptr, nullptr};  // host-buffer pipeline over caller-pinned memory (created on first use)
     // host-buffer pipeline over PAGEABLE caller memory: library-owned page-locked staging, one lane per worker thread
     // (stream + pinned in/out chunk + device in/out chunk), created on first use and kept
-    struct Lane {
-        hipStream_t st = nullptr;
+    struct Slot {  // one chunk in flight: page-locked staging pair, device pair, completion event
         void* h_in = nullptr;
         void* h_out = nullptr;
         void* d_in = nullptr;
         void* d_out = nullptr;
         size_t in_cap = 0, out_cap = 0;
+        hipEvent_t done = nullptr;
+    };
+    struct Lane {  // one worker thread + stream, double-buffered: the host copy of chunk c+1 overlaps the DMA / kernel of chunk c
+        hipStream_t st = nullptr;
+        Slot slot[2];
     };
     std::vector<Lane> lanes;
     // encryption: the sponge-call program of the last (variant, message_len) used, uploaded once (k_crypt interprets it)
@@ -177,10 +181,13 @@ void p252_destroy(p252_ctx* ctx) {
     if (ctx->d_prog) (void)hipFree(ctx->d_prog);
     for (auto& l : ctx->lanes) {
         if (l.st) (void)hipStreamDestroy(l.st);
-        if (l.h_in) (void)hipHostFree(l.h_in);
-        if (l.h_out) (void)hipHostFree(l.h_out);
-        if (l.d_in) (void)hipFree(l.d_in);
-        if (l.d_out) (void)hipFree(l.d_out);
+        for (auto& sl : l.slot) {
+            if (sl.h_in) (void)hipHostFree(sl.h_in);
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+            if (sl.d_in) (void)hipFree(sl.d_in);
+            if (sl.d_out) (void)hipFree(sl.d_out);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        }
     }
     delete ctx;
 }
@@ -325,21 +332,24 @@ static bool is_pinned(const void* p) {
 }
 
 // Pageable caller memory (a Rust Vec<BlsScalar>, a numpy array): page-locking it per call costs as much as the transfer
-// (round 1: 1.9e8 digests/s against 4.0e8 from pinned memory), and one thread copying into a staging buffer moves
-// ~10 GB/s where the Merkle4 stream needs ~60.  So the call is split into chunks handled by LANES worker threads, each
-// with its own page-locked staging pair, device chunk pair and stream:  memcpy in -> H2D -> kernel -> D2H -> memcpy out.
-// The host copies of one lane overlap the DMA and kernels of the others; nothing the caller owns is ever registered.
+// (round 1: 1.9e8 digests/s against 4.0e8 from pinned memory).  So the call is split into chunks handled by a few LANES:
+// a worker thread with its own stream and TWO slots (page-locked staging pair + device pair + event).  Per chunk:
+// memcpy in -> H2D -> kernel -> D2H (all asynchronous on the lane's stream) and, one chunk later, memcpy out — the host
+// copies of chunk c+1 overlap the DMA and kernel of chunk c, the lanes overlap each other, and nothing the caller owns is
+// ever registered.  Events are blocking-sync: a waiting worker sleeps instead of spinning (the benchmark box grants 16
+// CPUs; spinning workers get the whole process throttled).  The host copies themselves are not the limit (EPYC 9575F:
+// memcpy 30 GB/s per thread, bench_tools/ntcopy.cpp; non-temporal stores changed nothing end to end) — in-flight
+// depth is: round 2's first version (one slot per lane, spinning waits, 8-12 lanes) reached 2.0-3.1e8.
 static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
                              uint64_t* out, size_t n, size_t chunk) {
-    // Lane count: the copies are CPU work, so it follows the CPU time this process may use (affinity mask and cgroup
-    // quota) — 3/4 of it, between 2 and 12.  Measured on the benchmark box (256 logical CPUs, quota 16): 12 lanes 3.1e8
-    // digests/s, 16 and more lanes 2.1e8 (the quota throttles the threads) — profiles/r02_host_path.txt.
-    // P252_HOST_LANES overrides.
     static const int lanes_wanted = [] {
         if (const char* e = std::getenv("P252_HOST_LANES")) {
             const int v = std::atoi(e);
             return v < 1 ? 1 : (v > 32 ? 32 : v);
         }
+        // Three lanes x two slots keep the PCIe link busy; MORE lanes are slower on the benchmark box (16 CPUs of cgroup
+        // budget, 256 visible): 3 lanes 3.6-3.8e8 digests/s, 6 lanes 3.1-3.3e8, 12 lanes 2.0-2.2e8
+        // (profiles/r02_host_path.txt).  Two when the process may use fewer than four CPUs.
         double cpus = (double)std::thread::hardware_concurrency();
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = (double)CPU_COUNT(&set);
@@ -352,8 +362,7 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
             }
             std::fclose(f);
         }
-        const int v = (int)(cpus * 0.75);
-        return v < 2 ? 2 : (v > 12 ? 12 : v);
+        return cpus < 4 ? 2 : 3;
     }();
     const size_t n_chunks = (n + chunk - 1) / chunk;
     const int n_lanes = (int)(n_chunks < (size_t)lanes_wanted ? n_chunks : (size_t)lanes_wanted);
@@ -362,23 +371,26 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
     for (int l = 0; l < n_lanes; ++l) {
         p252_ctx::Lane& L = ctx->lanes[l];
         if (!L.st) HIP_TRY(ctx, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
-        if (L.in_cap < in_chunk_b) {
-            if (L.h_in) (void)hipHostFree(L.h_in);
-            if (L.d_in) (void)hipFree(L.d_in);
-            L.h_in = L.d_in = nullptr;
-            L.in_cap = 0;
-            HIP_TRY(ctx, hipHostMalloc(&L.h_in, in_chunk_b, hipHostMallocDefault));
-            HIP_TRY(ctx, hipMalloc(&L.d_in, in_chunk_b));
-            L.in_cap = in_chunk_b;
-        }
-        if (L.out_cap < out_chunk_b) {
-            if (L.h_out) (void)hipHostFree(L.h_out);
-            if (L.d_out) (void)hipFree(L.d_out);
-            L.h_out = L.d_out = nullptr;
-            L.out_cap = 0;
-            HIP_TRY(ctx, hipHostMalloc(&L.h_out, out_chunk_b, hipHostMallocDefault));
-            HIP_TRY(ctx, hipMalloc(&L.d_out, out_chunk_b));
-            L.out_cap = out_chunk_b;
+        for (auto& S : L.slot) {
+            if (!S.done) HIP_TRY(ctx, hipEventCreateWithFlags(&S.done, hipEventBlockingSync | hipEventDisableTiming));
+            if (S.in_cap < in_chunk_b) {
+                if (S.h_in) (void)hipHostFree(S.h_in);
+                if (S.d_in) (void)hipFree(S.d_in);
+                S.h_in = S.d_in = nullptr;
+                S.in_cap = 0;
+                HIP_TRY(ctx, hipHostMalloc(&S.h_in, in_chunk_b, hipHostMallocDefault));
+                HIP_TRY(ctx, hipMalloc(&S.d_in, in_chunk_b));
+                S.in_cap = in_chunk_b;
+            }
+            if (S.out_cap < out_chunk_b) {
+                if (S.h_out) (void)hipHostFree(S.h_out);
+                if (S.d_out) (void)hipFree(S.d_out);
+                S.h_out = S.d_out = nullptr;
+                S.out_cap = 0;
+                HIP_TRY(ctx, hipHostMalloc(&S.h_out, out_chunk_b, hipHostMallocDefault));
+                HIP_TRY(ctx, hipMalloc(&S.d_out, out_chunk_b));
+                S.out_cap = out_chunk_b;
+            }
         }
     }
     std::atomic<size_t> next{0};
@@ -398,32 +410,53 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
         };
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess) return bad("hipSetDevice", e);
+        long pending[2] = {-1, -1};  // chunk whose result sits (or will sit) in the slot's h_out
+        auto retire = [&](int k) {    // wait for slot k's chunk and hand its outputs to the caller
+            if (pending[k] < 0) return true;
+            const hipError_t w = hipEventSynchronize(L.slot[k].done);
+            if (w != hipSuccess) { bad("event sync", w); return false; }
+            const size_t off = (size_t)pending[k] * chunk, cnt = n - off < chunk ? n - off : chunk;
+            std::memcpy(reinterpret_cast<char*>(out) + off * out_len * 32, L.slot[k].h_out, cnt * out_len * 32);
+            pending[k] = -1;
+            return true;
+        };
+        int k = 0;
         for (;;) {
             const size_t c = next.fetch_add(1);
-            if (c >= n_chunks || status.load() != P252_OK) return;
+            if (c >= n_chunks || status.load() != P252_OK) break;
+            if (!retire(k)) return;
+            p252_ctx::Slot& S = L.slot[k];
             const size_t off = c * chunk, cnt = n - off < chunk ? n - off : chunk;
-            std::memcpy(L.h_in, reinterpret_cast<const char*>(in) + off * in_len * 32, cnt * in_len * 32);
-            e = hipMemcpyAsync(L.d_in, L.h_in, cnt * in_len * 32, hipMemcpyHostToDevice, L.st);
+            std::memcpy(S.h_in, reinterpret_cast<const char*>(in) + off * in_len * 32, cnt * in_len * 32);
+            e = hipMemcpyAsync(S.d_in, S.h_in, cnt * in_len * 32, hipMemcpyHostToDevice, L.st);
             if (e != hipSuccess) return bad("H2D", e);
             if (single)
-                e = launch_merkle4(ctx->d_tab, targ, L.d_in, 4 * cnt, L.d_out, cnt, L.st);
+                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 4 * cnt, S.d_out, cnt, L.st);
             else if (pair)
-                e = launch_merkle4(ctx->d_tab, targ, L.d_in, 2 * cnt, L.d_out, cnt, L.st, 2);
+                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 2 * cnt, S.d_out, cnt, L.st, 2);
             else
-                e = launch_sponge(ctx->d_tab, targ, L.d_in, (unsigned)in_len, (unsigned)out_len, L.d_out, cnt, L.st);
+                e = launch_sponge(ctx->d_tab, targ, S.d_in, (unsigned)in_len, (unsigned)out_len, S.d_out, cnt, L.st);
             if (e != hipSuccess) return bad("kernel launch", e);
-            e = hipMemcpyAsync(L.h_out, L.d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, L.st);
+            e = hipMemcpyAsync(S.h_out, S.d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, L.st);
             if (e != hipSuccess) return bad("D2H", e);
-            e = hipStreamSynchronize(L.st);
-            if (e != hipSuccess) return bad("stream sync", e);
-            std::memcpy(reinterpret_cast<char*>(out) + off * out_len * 32, L.h_out, cnt * out_len * 32);
+            e = hipEventRecord(S.done, L.st);
+            if (e != hipSuccess) return bad("event record", e);
+            pending[k] = (long)c;
+            k ^= 1;
         }
+        // drain, older chunk first (slot k holds the older one)
+        if (!retire(k)) return;
+        retire(k ^ 1);
+        if (status.load() != P252_OK) (void)hipStreamSynchronize(L.st);  // never leave work in flight on the staging buffers
     };
     std::vector<std::thread> pool;
     for (int l = 1; l < n_lanes; ++l) pool.emplace_back(work, l);
     work(0);
     for (auto& t : pool) t.join();
-    if (status.load() != P252_OK) return fail(ctx, status.load(), err);
+    if (status.load() != P252_OK) {
+        for (int l = 0; l < n_lanes; ++l) (void)hipStreamSynchronize(ctx->lanes[l].st);
+        return fail(ctx, status.load(), err);
+    }
     return P252_OK;
 }
 
@@ -444,7 +477,7 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
     }();
     static const size_t chunk_bytes_target = [] {  // P252_HOST_CHUNK_MB (developer switch): staging / DMA chunk size
         const char* e = std::getenv("P252_HOST_CHUNK_MB");
-        const int mb = e ? std::atoi(e) : 16;
+        const int mb = e ? std::atoi(e) : 8;
         return (size_t)(mb < 1 ? 1 : (mb > 256 ? 256 : mb)) << 20;
     }();
     size_t chunk = chunk_bytes_target / ((in_len > out_len ? in_len : out_len) * 32);
