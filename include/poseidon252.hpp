@@ -228,4 +228,80 @@ inline BlsScalar merkle4_root(const std::vector<BlsScalar>& leaves, Context& ctx
     return root;
 }
 
+// ---- several GPUs from one process: one Context per device, sharded inside the library (p252_*_multi) ----
+// digests[i*output_len..] == Hash::digest(domain, item i); contiguous shards, no inter-GPU dependence
+inline std::vector<BlsScalar> digest_multi(const std::vector<Context*>& ctxs, const HashBatch& hb, std::size_t item_len,
+                                           const std::vector<BlsScalar>& input) {
+    if (ctxs.empty() || item_len == 0 || input.size() % item_len) throw std::invalid_argument("digest_multi: bad arguments");
+    std::vector<p252_ctx*> raw;
+    for (Context* c : ctxs) raw.push_back(c->get());
+    const std::size_t n = input.size() / item_len;
+    std::vector<BlsScalar> out(n * hb.output_len());
+    if (n)
+        detail::check(p252_hash_batch_multi(raw.data(), raw.size(), hb.tag().data(), input[0].data(), item_len, hb.output_len(),
+                                            out[0].data(), n),
+                      raw[0], "digest_multi");
+    return out;
+}
+// root of the arity-4 tree over ctxs.size() * 4^k leaves: one complete subtree per device, 32-byte roots gathered on the host
+inline BlsScalar merkle4_root_multi(const std::vector<Context*>& ctxs, const std::vector<BlsScalar>& leaves) {
+    if (ctxs.empty() || leaves.empty()) throw std::invalid_argument("merkle4_root_multi: bad arguments");
+    std::vector<p252_ctx*> raw;
+    for (Context* c : ctxs) raw.push_back(c->get());
+    const BlsScalar tag = compute_tag(Domain::Merkle4, {4}, 1);
+    BlsScalar root{};
+    detail::check(p252_merkle4_tree_multi(raw.data(), raw.size(), tag.data(), leaves[0].data(), leaves.size(), root.data()), raw[0],
+                  "merkle4_root_multi");
+    return root;
+}
+
+// ---- dusk_poseidon::encrypt / decrypt (src/encryption.rs:62-95), batched; `variant` = P252_CRYPT_STREAM (default) or
+// P252_CRYPT_DUPLEX — the construction is UNPINNED.  secrets[i] = {shared.get_u(), shared.get_v()}. ----
+struct DecryptionFailed : std::runtime_error {  // dusk_poseidon::Error::DecryptionFailed (src/error.rs:27-29)
+    DecryptionFailed() : std::runtime_error("DecryptionFailed") {}
+};
+inline BlsScalar encryption_tag(std::size_t message_len, int variant = P252_CRYPT_STREAM) {
+    BlsScalar t{};
+    detail::check(p252_encryption_tag(variant, message_len, t.data()), nullptr, "encryption_tag");
+    return t;
+}
+inline std::vector<BlsScalar> encrypt_batch(const std::vector<BlsScalar>& messages, std::size_t message_len,
+                                            const std::vector<BlsScalar>& secrets, const std::vector<BlsScalar>& nonces,
+                                            int variant = P252_CRYPT_STREAM, Context& ctx = Context::default_context()) {
+    const std::size_t n = nonces.size();
+    if (messages.size() != n * message_len || secrets.size() != 2 * n) throw std::invalid_argument("encrypt_batch: sizes");
+    const BlsScalar tag = encryption_tag(message_len, variant);
+    std::vector<BlsScalar> out(n * (message_len + 1));
+    if (n)
+        detail::check(p252_encrypt_batch(ctx.get(), variant, tag.data(), messages[0].data(), secrets[0].data(), nonces[0].data(), message_len,
+                                         out[0].data(), n),
+                      ctx.get(), "encrypt_batch");
+    return out;
+}
+// returns the messages; ok[i] == 0 marks an item whose MAC did not verify (its message is unspecified)
+inline std::vector<BlsScalar> decrypt_batch(const std::vector<BlsScalar>& ciphers, std::size_t message_len,
+                                            const std::vector<BlsScalar>& secrets, const std::vector<BlsScalar>& nonces,
+                                            std::vector<std::uint8_t>& ok, int variant = P252_CRYPT_STREAM,
+                                            Context& ctx = Context::default_context()) {
+    const std::size_t n = nonces.size();
+    if (ciphers.size() != n * (message_len + 1) || secrets.size() != 2 * n) throw std::invalid_argument("decrypt_batch: sizes");
+    const BlsScalar tag = encryption_tag(message_len, variant);
+    std::vector<BlsScalar> out(n * message_len);
+    ok.assign(n, 0);
+    if (n)
+        detail::check(p252_decrypt_batch(ctx.get(), variant, tag.data(), ciphers[0].data(), secrets[0].data(), nonces[0].data(), message_len,
+                                         out[0].data(), ok.data(), n),
+                      ctx.get(), "decrypt_batch");
+    return out;
+}
+// single message, the reference's call shape: throws DecryptionFailed like decrypt() returns Err
+inline std::vector<BlsScalar> decrypt(const std::vector<BlsScalar>& cipher, const BlsScalar& secret_u, const BlsScalar& secret_v,
+                                      const BlsScalar& nonce, int variant = P252_CRYPT_STREAM, Context& ctx = Context::default_context()) {
+    if (cipher.size() < 2) throw IoPatternError(IoPatternError::InvalidIOPattern, "decrypt: empty message");
+    std::vector<std::uint8_t> ok;
+    auto m = decrypt_batch(cipher, cipher.size() - 1, {secret_u, secret_v}, {nonce}, ok, variant, ctx);
+    if (!ok[0]) throw DecryptionFailed();
+    return m;
+}
+
 }  // namespace dusk_poseidon_hip

@@ -3,6 +3,7 @@
 // truncated, multi-output (3,3) (5,2) (4,7)), src/hades.rs:94-162 (known-answer test, through the HIP
 // sponge with tag = 0), src/hash.rs:124-137 (panics -> exceptions).  The oracle (oracle/p252_oracle.h)
 // is linked as the checker only.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -152,6 +153,53 @@ int main() {
         {  // caller-owned buffer page-locked for the scope: same digests
             HostRegistration reg(input.data(), input.size() * sizeof(BlsScalar));
             EXPECT(hb.digest(input) == got);
+        }
+    }
+    // ---- several contexts (one per GPU; here all on device 0): same bytes as one context, sharded tree root ----
+    {
+        Context c0(0), c1(0), c2(0), c3(0);
+        std::vector<Context*> ctxs = {&c0, &c1, &c2, &c3};
+        HashBatch hb(Domain::Merkle4, 4);
+        auto input = random_scalars(0xabc, 4 * 1001);
+        EXPECT(digest_multi(ctxs, hb, 4, input) == hb.digest(input));
+        auto leaves = random_scalars(11, 4 * 256);  // 4 complete subtrees of 4^4 leaves
+        EXPECT(merkle4_root_multi(ctxs, leaves) == merkle4_root(leaves));
+        bool threw = false;
+        try {
+            merkle4_root_multi(ctxs, random_scalars(12, 4 * 100));  // 100 leaves per device: not 4^k
+        } catch (const std::invalid_argument&) {
+            threw = true;
+        }
+        EXPECT(threw);
+    }
+    // ---- encrypt / decrypt (src/encryption.rs:62-95; tests/encryption.rs properties), both call sequences ----
+    for (int variant : {P252_CRYPT_STREAM, P252_CRYPT_DUPLEX}) {
+        for (std::size_t len : {std::size_t(2), std::size_t(21), std::size_t(42)}) {
+            const std::size_t n = 17;
+            auto msgs = random_scalars(100 + len, n * len), secrets = random_scalars(200 + len, 2 * n), nonces = random_scalars(300 + len, n);
+            auto cipher = encrypt_batch(msgs, len, secrets, nonces, variant);
+            EXPECT(cipher.size() == n * (len + 1));
+            std::vector<BlsScalar> exp(n * (len + 1));
+            const BlsScalar tag = encryption_tag(len, variant);
+            for (std::size_t i = 0; i < n; ++i)
+                p252o_encrypt_v(variant, tag.data(), msgs[i * len].data(), len, secrets[2 * i].data(), nonces[i].data(), exp[i * (len + 1)].data());
+            EXPECT(cipher == exp);
+            std::vector<std::uint8_t> ok;
+            EXPECT(decrypt_batch(cipher, len, secrets, nonces, ok, variant) == msgs);
+            EXPECT(std::all_of(ok.begin(), ok.end(), [](std::uint8_t v) { return v == 1; }));
+            auto wrong = nonces;
+            std::swap(wrong[0], wrong[1]);
+            decrypt_batch(cipher, len, secrets, wrong, ok, variant);
+            EXPECT(ok[0] == 0 && ok[1] == 0 && ok[2] == 1);  // wrong nonce -> DecryptionFailed for exactly those items
+            std::vector<BlsScalar> one(cipher.begin(), cipher.begin() + len + 1);
+            EXPECT(decrypt(one, secrets[0], secrets[1], nonces[0], variant) == std::vector<BlsScalar>(msgs.begin(), msgs.begin() + len));
+            bool failed = false;
+            try {
+                decrypt(one, secrets[1], secrets[0], nonces[0], variant);
+            } catch (const DecryptionFailed&) {
+                failed = true;
+            }
+            EXPECT(failed);
         }
     }
     std::printf(failures ? "C++ HOST API: %d FAILURES\n" : "C++ HOST API: ALL PASSED\n", failures);
