@@ -40,10 +40,10 @@ __device__ __forceinline__ void store_scalar(Scalar32* __restrict__ p, const E29
 }
 
 // ---- n independent permutations (Safe::permute, scalar.rs:25-27) ----
-// (k_permute and k_sponge keep all five lanes: held at 3 waves per SIMD they spill 15-19 registers to scratch (60-76 B
-// per lane, touched outside the partial-round loop) and are still 1 % faster than at 2 waves without spills — same-box
-// A/B on config 4, profiles/r02_ab_occupancy.txt; k_crypt gains nothing and stays at 2 waves)
-__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_permute(const int32_t* __restrict__ tab,
+// (k_permute, k_sponge and k_crypt keep all five lanes: 205-225 VGPRs = 2 waves per SIMD.  Held at 3 waves they spill
+// 15-19 registers to scratch and gain 1 % on config 4 (same-box A/B, profiles/r02_ab_occupancy.txt) — at the price of
+// tripling the kernel's HBM write traffic; not taken.)
+__global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restrict__ tab,
                                                         const Scalar32* __restrict__ in,
                                                         Scalar32* __restrict__ out, size_t n) {
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_pad(const int32_t* __res
 // ---- generic sponge: n messages, same (in_len, out_len).  dusk-safe mechanics:
 // absorb 4 elements per permutation into state[1..4]; first squeeze always permutes; 4 outputs per
 // permutation.  One inlined permutation call site. ----
-__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_sponge(const int32_t* __restrict__ tab, TagArg tag,
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict__ tab, TagArg tag,
                                                        const Scalar32* __restrict__ in, unsigned in_len,
                                                        unsigned out_len, Scalar32* __restrict__ out,
                                                        size_t n) {
