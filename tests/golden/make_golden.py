@@ -50,6 +50,19 @@ def main():
         root, perms = oracle.merkle4_tree(tag, lv)
         trees.append({"n_leaves": n, "seed": 0x3000 + n, "root": hx(root), "perms": int(perms)})
     out["merkle4_tree"] = trees
+    # encryption (src/encryption.rs:62-95): both candidate call sequences (oracle/p252_oracle.h), message lengths incl. the
+    # reference tests' 21 and 42 (tests/encryption.rs:33,49); UNPINNED against the real dusk-safe
+    enc = []
+    for variant in (0, 1):
+        for ln in (2, 5, 21, 42):
+            seed = 0x4000 + 100 * variant + ln
+            tag = oracle.encryption_tag(ln, variant)
+            msgs = oracle.fill_random(seed, 2 * ln).reshape(2, ln, 4)
+            secrets = oracle.fill_random(seed + 1, 4).reshape(2, 2, 4)
+            nonces = oracle.fill_random(seed + 2, 2)
+            enc.append({"variant": variant, "len": ln, "seed": seed, "n": 2, "tag_UNPINNED": hx(tag),
+                        "cipher": hx(oracle.encrypt_batch(tag, msgs, secrets, nonces, variant))})
+    out["encrypt_UNPINNED"] = enc
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -233,3 +233,34 @@ def test_gpu_encrypt_device_buffers(gpu_ctx, oracle_mod, variant):
     torch.cuda.synchronize()
     assert np.array_equal(d_c.cpu().numpy().view(np.uint64), oracle_mod.encrypt_batch(tag, msgs, secrets, nonces, variant))
     assert bool(d_ok.all()) and torch.equal(d_back, d_m)
+
+
+def _gold():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["encrypt_UNPINNED"]
+
+
+def _gold_case(oracle_mod, c):
+    ln, seed = c["len"], c["seed"]
+    msgs = oracle_mod.fill_random(seed, 2 * ln).reshape(2, ln, 4)
+    secrets = oracle_mod.fill_random(seed + 1, 4).reshape(2, 2, 4)
+    nonces = oracle_mod.fill_random(seed + 2, 2)
+    tag = np.array([int(h, 16) for h in c["tag_UNPINNED"]], dtype=np.uint64)
+    exp = np.array([int(h, 16) for h in c["cipher"]], dtype=np.uint64).reshape(2, ln + 1, 4)
+    return msgs, secrets, nonces, tag, exp
+
+
+def test_oracle_reproduces_the_committed_encryption_vectors(oracle_mod):
+    """tests/golden/vectors.json freezes both call sequences (oracle and kernels cannot drift together unnoticed)"""
+    for c in _gold():
+        msgs, secrets, nonces, tag, exp = _gold_case(oracle_mod, c)
+        assert np.array_equal(oracle_mod.encryption_tag(c["len"], c["variant"]), tag)
+        assert np.array_equal(oracle_mod.encrypt_batch(tag, msgs, secrets, nonces, c["variant"]), exp)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_committed_encryption_vectors(gpu_ctx, oracle_mod):
+    from poseidon252_amd.encryption import encrypt_batch
+    for c in _gold():
+        msgs, secrets, nonces, tag, exp = _gold_case(oracle_mod, c)
+        assert np.array_equal(encrypt_batch(msgs, secrets, nonces, ctx=gpu_ctx, tag=tag, variant=c["variant"]), exp)
