@@ -86,3 +86,53 @@ def test_sharded_tree_rejects_incomplete_subtrees():
     root = D.merkle4_tree_sharded(torch.zeros((5, 4), dtype=torch.int64), np.zeros(4, dtype=np.uint64),
                                   subtree_fn=lambda lv: np.arange(4, dtype=np.uint64), top_fn=None)
     assert np.array_equal(root, np.arange(4, dtype=np.uint64))
+
+
+class _FakeCtx:
+    """stands in for poseidon252_amd.Context where no GPU exists: only the two table calls broadcast_tables uses"""
+
+    def __init__(self, table):
+        self.table, self.imported = table, None
+
+    def tables_export(self):
+        return self.table.copy()
+
+    def tables_import(self, t):
+        self.imported = np.asarray(t).copy()
+
+
+def _bcast_worker(rank, world, port, corrupt, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    table = np.arange(5000, dtype=np.int32)
+    if corrupt and rank == 1:
+        table[1234] ^= 1  # this rank's library derived something else (mismatched build / corrupted memory)
+    ctx = _FakeCtx(table)
+    try:
+        same = D.broadcast_tables(ctx)
+        out_q.put((rank, "ok", bool(same), ctx.imported is not None and np.array_equal(ctx.imported, np.arange(5000, dtype=np.int32))))
+    except RuntimeError as e:
+        out_q.put((rank, "raised", "differs" in str(e), ctx.imported is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_broadcast_tables_raises_on_a_mismatching_rank(corrupt):
+    """a table that differs from the local derivation must never be imported silently"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, corrupt, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if not corrupt:
+        assert got == [(0, "ok", True, True), (1, "ok", True, True)]
+    else:
+        assert got[0] == (0, "ok", True, True)          # rank 0 is the source: its own table
+        assert got[1] == (1, "raised", True, True)      # rank 1 refuses the import
