@@ -340,8 +340,10 @@ static bool is_pinned(const void* p) {
 // CPUs; spinning workers get the whole process throttled).  The host copies themselves are not the limit (EPYC 9575F:
 // memcpy 30 GB/s per thread, bench_tools/ntcopy.cpp; non-temporal stores changed nothing end to end) — in-flight
 // depth is: round 2's first version (one slot per lane, spinning waits, 8-12 lanes) reached 2.0-3.1e8.
+// d_resident_out != NULL: the outputs stay on the device (item i at d_resident_out + i * out_len * 32) — the first level of a
+// tree built from host leaves; `out` is then unused.
 static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
-                             uint64_t* out, size_t n, size_t chunk) {
+                             uint64_t* out, size_t n, size_t chunk, char* d_resident_out = nullptr) {
     static const int lanes_wanted = [] {
         if (const char* e = std::getenv("P252_HOST_LANES")) {
             const int v = std::atoi(e);
@@ -415,8 +417,10 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
             if (pending[k] < 0) return true;
             const hipError_t w = hipEventSynchronize(L.slot[k].done);
             if (w != hipSuccess) { bad("event sync", w); return false; }
-            const size_t off = (size_t)pending[k] * chunk, cnt = n - off < chunk ? n - off : chunk;
-            std::memcpy(reinterpret_cast<char*>(out) + off * out_len * 32, L.slot[k].h_out, cnt * out_len * 32);
+            if (!d_resident_out) {
+                const size_t off = (size_t)pending[k] * chunk, cnt = n - off < chunk ? n - off : chunk;
+                std::memcpy(reinterpret_cast<char*>(out) + off * out_len * 32, L.slot[k].h_out, cnt * out_len * 32);
+            }
             pending[k] = -1;
             return true;
         };
@@ -430,15 +434,18 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
             std::memcpy(S.h_in, reinterpret_cast<const char*>(in) + off * in_len * 32, cnt * in_len * 32);
             e = hipMemcpyAsync(S.d_in, S.h_in, cnt * in_len * 32, hipMemcpyHostToDevice, L.st);
             if (e != hipSuccess) return bad("H2D", e);
+            void* d_dst = d_resident_out ? static_cast<void*>(d_resident_out + off * out_len * 32) : S.d_out;
             if (single)
-                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 4 * cnt, S.d_out, cnt, L.st);
+                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 4 * cnt, d_dst, cnt, L.st);
             else if (pair)
-                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 2 * cnt, S.d_out, cnt, L.st, 2);
+                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 2 * cnt, d_dst, cnt, L.st, 2);
             else
-                e = launch_sponge(ctx->d_tab, targ, S.d_in, (unsigned)in_len, (unsigned)out_len, S.d_out, cnt, L.st);
+                e = launch_sponge(ctx->d_tab, targ, S.d_in, (unsigned)in_len, (unsigned)out_len, d_dst, cnt, L.st);
             if (e != hipSuccess) return bad("kernel launch", e);
-            e = hipMemcpyAsync(S.h_out, S.d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, L.st);
-            if (e != hipSuccess) return bad("D2H", e);
+            if (!d_resident_out) {
+                e = hipMemcpyAsync(S.h_out, S.d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, L.st);
+                if (e != hipSuccess) return bad("D2H", e);
+            }
             e = hipEventRecord(S.done, L.st);
             if (e != hipSuccess) return bad("event record", e);
             pending[k] = (long)c;
@@ -538,15 +545,30 @@ static int merkle_tree_host(p252_ctx* ctx, unsigned arity, const uint64_t tag[4]
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t leaf_bytes = n_leaves * 32;
     const size_t lvl_bytes = levels_len(n_leaves, arity) * 32;
-    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, leaf_bytes);
+    int rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, (levels ? lvl_bytes : 0) + 32);
     if (rc) return rc;
-    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, (levels ? lvl_bytes : 0) + 32);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(ctx->d_in, leaves, leaf_bytes, hipMemcpyHostToDevice));
     char* d_root = static_cast<char*>(ctx->d_out);
     char* d_levels = levels ? d_root + 32 : nullptr;
-    rc = merkle_tree_device(ctx, arity, tag, ctx->d_in, n_leaves, d_root, d_levels, nullptr);
-    if (rc) return rc;
+    const size_t n_l1 = n_leaves / arity;
+    const size_t chunk_nodes = (((size_t)8 << 20) / (arity * 32)) & ~(size_t)255;  // 8 MiB of leaves per chunk
+    if (n_leaves % arity == 0 && n_l1 >= 4 * chunk_nodes && !is_pinned(leaves)) {
+        // Big tree from pageable host memory (512 MiB of leaves at 2^24): the upload would take longer than the whole build.
+        // The first level is hashed chunk by chunk WHILE the leaves stream in through the staging lanes (its nodes stay on
+        // the device); the remaining levels run as usual.  The leaves themselves are never resident as a whole.
+        rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, n_l1 * 32);
+        if (rc) return rc;
+        char* d_l1 = levels ? d_levels : static_cast<char*>(ctx->d_in);
+        rc = hash_batch_staged(ctx, tag, leaves, arity, 1, nullptr, n_l1, chunk_nodes, d_l1);
+        if (rc) return rc;
+        rc = merkle_tree_device(ctx, arity, tag, d_l1, n_l1, d_root, levels ? d_levels + n_l1 * 32 : nullptr, nullptr);
+        if (rc) return rc;
+    } else {
+        rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, leaf_bytes);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->d_in, leaves, leaf_bytes, hipMemcpyHostToDevice));
+        rc = merkle_tree_device(ctx, arity, tag, ctx->d_in, n_leaves, d_root, d_levels, nullptr);
+        if (rc) return rc;
+    }
     HIP_TRY(ctx, hipMemcpy(root, d_root, 32, hipMemcpyDeviceToHost));
     if (levels && lvl_bytes) HIP_TRY(ctx, hipMemcpy(levels, d_levels, lvl_bytes, hipMemcpyDeviceToHost));
     return P252_OK;

@@ -75,3 +75,26 @@ def test_staged_lanes_mixed_memory_and_lane_counts(gpu_ctx, oracle_mod):
     ctx2 = P.Context(0)
     assert np.array_equal(ctx2.hash_batch(hb.tag, x, 4, 1).reshape(ref.shape), ref)
     ctx2.close()
+
+
+def test_tree_from_pageable_host_leaves_streams_the_first_level(gpu_ctx, oracle_mod):
+    """p252_merkle4_tree / p252_merkle2_tree on big pageable leaf arrays: the first level is hashed chunk by chunk while
+    the leaves stream in through the staging lanes; root and all levels must equal the device-resident build"""
+    import torch
+    import poseidon252_amd as P
+    tag = P.merkle4_tag()
+    for n in (1 << 20, (1 << 20) + 4 * 70000, 1 << 21):  # 4 / 5+ / 8 chunks of 2^16 level-1 nodes, ragged last chunk
+        lv = oracle_mod.fill_random(0xabc0 + n % 1000, n)
+        root, levels = gpu_ctx.merkle4_tree(tag, lv, want_levels=True)
+        d = torch.from_numpy(lv.view(np.int64)).cuda()
+        d_root, d_levels = P.merkle4_tree(d, tag=tag, ctx=gpu_ctx, want_levels=True)
+        assert np.array_equal(root, d_root.cpu().numpy().view(np.uint64))
+        assert np.array_equal(levels, d_levels.cpu().numpy().view(np.uint64))
+        assert np.array_equal(gpu_ctx.merkle4_tree(tag, lv), root)  # root-only variant (level 1 in scratch)
+        idx = np.arange(0, n // 4, 9973)
+        assert np.array_equal(levels[idx], oracle_mod.hash_batch(tag, lv.reshape(-1, 4, 4)[idx], 4, 1).reshape(-1, 4))
+    tag2 = oracle_mod.tag(1, [2], 1)
+    lv = oracle_mod.fill_random(0xabc9, 1 << 20)
+    r2, l2 = gpu_ctx.merkle2_tree(tag2, lv, want_levels=True)
+    o2 = oracle_mod.merkle2_tree(tag2, lv, want_levels=True)
+    assert np.array_equal(r2, o2[0]) and np.array_equal(l2, o2[1])
