@@ -307,23 +307,6 @@ int p252_merkle2_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
 // ------------------------------------------------------------------------------------------
 // host-buffer entry points (synchronous)
 // ------------------------------------------------------------------------------------------
-int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
-    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
-    if (n == 0) return P252_OK;
-    if (!states || !out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "permute: NULL buffer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = n * P252_HADES_WIDTH * 32;
-    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, bytes);
-    if (rc) return rc;
-    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, bytes);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(ctx->d_in, states, bytes, hipMemcpyHostToDevice));
-    rc = p252_permute_batch_device(ctx, ctx->d_in, ctx->d_out, n, nullptr);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, bytes, hipMemcpyDeviceToHost));
-    return P252_OK;
-}
-
 static bool is_pinned(const void* p) {
     hipPointerAttribute_t a;
     const bool is = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
@@ -332,19 +315,23 @@ static bool is_pinned(const void* p) {
 }
 
 // Pageable caller memory (a Rust Vec<BlsScalar>, a numpy array): page-locking it per call costs as much as the transfer
-// (round 1: 1.9e8 digests/s against 4.0e8 from pinned memory).  So the call is split into chunks handled by a few LANES:
-// a worker thread with its own stream and TWO slots (page-locked staging pair + device pair + event).  Per chunk:
-// memcpy in -> H2D -> kernel -> D2H (all asynchronous on the lane's stream) and, one chunk later, memcpy out — the host
-// copies of chunk c+1 overlap the DMA and kernel of chunk c, the lanes overlap each other, and nothing the caller owns is
-// ever registered.  Events are blocking-sync: a waiting worker sleeps instead of spinning (the benchmark box grants 16
-// CPUs; spinning workers get the whole process throttled).  The host copies themselves are not the limit (EPYC 9575F:
-// memcpy 30 GB/s per thread, bench_tools/ntcopy.cpp; non-temporal stores changed nothing end to end) — in-flight
-// depth is: round 2's first version (one slot per lane, spinning waits, 8-12 lanes) reached 2.0-3.1e8.
-// d_resident_out != NULL: the outputs stay on the device (item i at d_resident_out + i * out_len * 32) — the first level of a
-// tree built from host leaves; `out` is then unused.
-static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
-                             uint64_t* out, size_t n, size_t chunk, char* d_resident_out = nullptr) {
-    static const int lanes_wanted = [] {
+// (round 1: 1.9e8 digests/s against 4.0e8 from pinned memory).  So a large host-buffer call is split into chunks of items
+// handled by a few LANES: a worker thread with its own stream and TWO slots (page-locked staging pair + device pair +
+// event).  Per chunk: memcpy in -> H2D -> kernel -> D2H (all asynchronous on the lane's stream) and, one chunk later,
+// memcpy out — the host copies of chunk c+1 overlap the DMA and kernel of chunk c, the lanes overlap each other, and
+// nothing the caller owns is ever registered.  Events are blocking-sync: a waiting worker sleeps instead of spinning (the
+// benchmark box grants 16 CPUs; spinning workers get the whole process throttled).  The host copies themselves are not
+// the limit (EPYC 9575F: memcpy 30 GB/s per thread, bench_tools/ntcopy.cpp; non-temporal stores changed nothing end to
+// end) — in-flight depth is: round 2's first version (one slot per lane, spinning waits, 8-12 lanes) reached 2.0-3.1e8.
+extern "C++" {  // (templates below; the enclosing block is extern "C")
+struct HostSpan {  // one per-item array of a batched call: item i occupies bytes [i * stride, (i + 1) * stride)
+    const char* src;  // input arrays: caller memory to read
+    char* dst;        // output arrays: caller memory to write
+    size_t stride;
+};
+
+static int staging_lanes_wanted() {
+    static const int lanes = [] {
         if (const char* e = std::getenv("P252_HOST_LANES")) {
             const int v = std::atoi(e);
             return v < 1 ? 1 : (v > 32 ? 32 : v);
@@ -366,10 +353,29 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
         }
         return cpus < 4 ? 2 : 3;
     }();
+    return lanes;
+}
+
+// Runs `launch(d_in[], d_out[], first_item, count, stream)` over n items in chunks of `chunk`, streaming the input arrays
+// in and the output arrays out through the staging lanes.  d_in[a] / d_out[a] are the device copies of chunk-local slices
+// of ins[a] / outs[a] (256-byte aligned).  `outs` may be empty (results stay on the device: the launch writes them itself).
+template <class Launch>
+static int staged_run(p252_ctx* ctx, size_t n, size_t chunk, const std::vector<HostSpan>& ins, const std::vector<HostSpan>& outs,
+                      Launch&& launch) {
     const size_t n_chunks = (n + chunk - 1) / chunk;
+    const int lanes_wanted = staging_lanes_wanted();
     const int n_lanes = (int)(n_chunks < (size_t)lanes_wanted ? n_chunks : (size_t)lanes_wanted);
     if ((int)ctx->lanes.size() < n_lanes) ctx->lanes.resize(n_lanes);
-    const size_t in_chunk_b = chunk * in_len * 32, out_chunk_b = chunk * out_len * 32;
+    auto layout = [&](const std::vector<HostSpan>& spans, std::vector<size_t>& offs) {  // sub-buffer offsets, total bytes
+        size_t total = 0;
+        for (const HostSpan& sp : spans) {
+            offs.push_back(total);
+            total += (chunk * sp.stride + 255) & ~(size_t)255;
+        }
+        return total ? total : (size_t)256;
+    };
+    std::vector<size_t> in_off, out_off;
+    const size_t in_chunk_b = layout(ins, in_off), out_chunk_b = layout(outs, out_off);
     for (int l = 0; l < n_lanes; ++l) {
         p252_ctx::Lane& L = ctx->lanes[l];
         if (!L.st) HIP_TRY(ctx, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
@@ -399,8 +405,6 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
     std::atomic<int> status{P252_OK};
     std::mutex err_mu;
     std::string err;
-    const TagArg targ = tag_arg(tag);
-    const bool single = in_len == 4 && out_len == 1, pair = in_len == 2 && out_len == 1;
     auto work = [&](int l) {
         p252_ctx::Lane& L = ctx->lanes[l];
         auto bad = [&](const char* what, hipError_t e) {
@@ -412,18 +416,19 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
         };
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess) return bad("hipSetDevice", e);
-        long pending[2] = {-1, -1};  // chunk whose result sits (or will sit) in the slot's h_out
+        long pending[2] = {-1, -1};  // chunk whose results sit (or will sit) in the slot's h_out
         auto retire = [&](int k) {    // wait for slot k's chunk and hand its outputs to the caller
             if (pending[k] < 0) return true;
             const hipError_t w = hipEventSynchronize(L.slot[k].done);
             if (w != hipSuccess) { bad("event sync", w); return false; }
-            if (!d_resident_out) {
-                const size_t off = (size_t)pending[k] * chunk, cnt = n - off < chunk ? n - off : chunk;
-                std::memcpy(reinterpret_cast<char*>(out) + off * out_len * 32, L.slot[k].h_out, cnt * out_len * 32);
-            }
+            const size_t off = (size_t)pending[k] * chunk, cnt = n - off < chunk ? n - off : chunk;
+            for (size_t a = 0; a < outs.size(); ++a)
+                std::memcpy(outs[a].dst + off * outs[a].stride, static_cast<char*>(L.slot[k].h_out) + out_off[a], cnt * outs[a].stride);
             pending[k] = -1;
             return true;
         };
+        std::vector<const void*> d_in(ins.size());
+        std::vector<void*> d_out(outs.size());
         int k = 0;
         for (;;) {
             const size_t c = next.fetch_add(1);
@@ -431,19 +436,19 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
             if (!retire(k)) return;
             p252_ctx::Slot& S = L.slot[k];
             const size_t off = c * chunk, cnt = n - off < chunk ? n - off : chunk;
-            std::memcpy(S.h_in, reinterpret_cast<const char*>(in) + off * in_len * 32, cnt * in_len * 32);
-            e = hipMemcpyAsync(S.d_in, S.h_in, cnt * in_len * 32, hipMemcpyHostToDevice, L.st);
-            if (e != hipSuccess) return bad("H2D", e);
-            void* d_dst = d_resident_out ? static_cast<void*>(d_resident_out + off * out_len * 32) : S.d_out;
-            if (single)
-                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 4 * cnt, d_dst, cnt, L.st);
-            else if (pair)
-                e = launch_merkle4(ctx->d_tab, targ, S.d_in, 2 * cnt, d_dst, cnt, L.st, 2);
-            else
-                e = launch_sponge(ctx->d_tab, targ, S.d_in, (unsigned)in_len, (unsigned)out_len, d_dst, cnt, L.st);
+            for (size_t a = 0; a < ins.size(); ++a) {
+                char* h = static_cast<char*>(S.h_in) + in_off[a];
+                char* d = static_cast<char*>(S.d_in) + in_off[a];
+                std::memcpy(h, ins[a].src + off * ins[a].stride, cnt * ins[a].stride);
+                e = hipMemcpyAsync(d, h, cnt * ins[a].stride, hipMemcpyHostToDevice, L.st);
+                if (e != hipSuccess) return bad("H2D", e);
+                d_in[a] = d;
+            }
+            for (size_t a = 0; a < outs.size(); ++a) d_out[a] = static_cast<char*>(S.d_out) + out_off[a];
+            e = launch(d_in.data(), d_out.data(), off, cnt, L.st);
             if (e != hipSuccess) return bad("kernel launch", e);
-            if (!d_resident_out) {
-                e = hipMemcpyAsync(S.h_out, S.d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, L.st);
+            for (size_t a = 0; a < outs.size(); ++a) {
+                e = hipMemcpyAsync(static_cast<char*>(S.h_out) + out_off[a], d_out[a], cnt * outs[a].stride, hipMemcpyDeviceToHost, L.st);
                 if (e != hipSuccess) return bad("D2H", e);
             }
             e = hipEventRecord(S.done, L.st);
@@ -454,18 +459,73 @@ static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_
         // drain, older chunk first (slot k holds the older one)
         if (!retire(k)) return;
         retire(k ^ 1);
-        if (status.load() != P252_OK) (void)hipStreamSynchronize(L.st);  // never leave work in flight on the staging buffers
     };
     std::vector<std::thread> pool;
     for (int l = 1; l < n_lanes; ++l) pool.emplace_back(work, l);
     work(0);
     for (auto& t : pool) t.join();
     if (status.load() != P252_OK) {
-        for (int l = 0; l < n_lanes; ++l) (void)hipStreamSynchronize(ctx->lanes[l].st);
+        for (int l = 0; l < n_lanes; ++l) (void)hipStreamSynchronize(ctx->lanes[l].st);  // never leave work in flight on the staging buffers
         return fail(ctx, status.load(), err);
     }
     return P252_OK;
 }
+
+// items per chunk so that a chunk moves about P252_HOST_CHUNK_MB (default 8) MiB, a multiple of the block size
+static size_t staging_chunk_items(size_t bytes_per_item) {
+    static const size_t chunk_bytes_target = [] {
+        const char* e = std::getenv("P252_HOST_CHUNK_MB");
+        const int mb = e ? std::atoi(e) : 8;
+        return (size_t)(mb < 1 ? 1 : (mb > 256 ? 256 : mb)) << 20;
+    }();
+    size_t chunk = chunk_bytes_target / (bytes_per_item ? bytes_per_item : 1);
+    if (chunk < 4096) chunk = 4096;
+    return chunk & ~(size_t)255;
+}
+
+// n sponge hashes through the staging lanes.  d_resident_out != NULL: the outputs stay on the device (item i at
+// d_resident_out + i * out_len * 32) — the first level of a tree built from host leaves; `out` is then unused.
+static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
+                             uint64_t* out, size_t n, size_t chunk, char* d_resident_out = nullptr) {
+    const TagArg targ = tag_arg(tag);
+    const bool single = in_len == 4 && out_len == 1, pair = in_len == 2 && out_len == 1;
+    std::vector<HostSpan> ins = {{reinterpret_cast<const char*>(in), nullptr, in_len * 32}}, outs;
+    if (!d_resident_out) outs.push_back({nullptr, reinterpret_cast<char*>(out), out_len * 32});
+    return staged_run(ctx, n, chunk, ins, outs, [&](const void* const* d_in, void* const* d_out, size_t off, size_t cnt, hipStream_t st) {
+        void* d_dst = d_resident_out ? static_cast<void*>(d_resident_out + off * out_len * 32) : d_out[0];
+        if (single) return launch_merkle4(ctx->d_tab, targ, d_in[0], 4 * cnt, d_dst, cnt, st);
+        if (pair) return launch_merkle4(ctx->d_tab, targ, d_in[0], 2 * cnt, d_dst, cnt, st, 2);
+        return launch_sponge(ctx->d_tab, targ, d_in[0], (unsigned)in_len, (unsigned)out_len, d_dst, cnt, st);
+    });
+}
+}  // extern "C++"
+
+int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, size_t n) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!states || !out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "permute: NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = n * P252_HADES_WIDTH * 32;
+    {
+        const size_t chunk = staging_chunk_items(P252_HADES_WIDTH * 32);
+        if (n >= 2 * chunk && !(is_pinned(states) && is_pinned(out)))  // large pageable batch: through the staging lanes
+            return staged_run(ctx, n, chunk, {{reinterpret_cast<const char*>(states), nullptr, P252_HADES_WIDTH * 32}},
+                              {{nullptr, reinterpret_cast<char*>(out), P252_HADES_WIDTH * 32}},
+                              [&](const void* const* d_in, void* const* d_out, size_t, size_t cnt, hipStream_t st) {
+                                  return launch_permute(ctx->d_tab, d_in[0], d_out[0], cnt, st);
+                              });
+    }
+    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, bytes);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, bytes);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_in, states, bytes, hipMemcpyHostToDevice));
+    rc = p252_permute_batch_device(ctx, ctx->d_in, ctx->d_out, n, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, bytes, hipMemcpyDeviceToHost));
+    return P252_OK;
+}
+
 
 int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
                     uint64_t* out, size_t n) {
@@ -482,14 +542,7 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
         const char* e = std::getenv("P252_HOST_PIPELINE");
         return e ? std::atoi(e) : 2;
     }();
-    static const size_t chunk_bytes_target = [] {  // P252_HOST_CHUNK_MB (developer switch): staging / DMA chunk size
-        const char* e = std::getenv("P252_HOST_CHUNK_MB");
-        const int mb = e ? std::atoi(e) : 8;
-        return (size_t)(mb < 1 ? 1 : (mb > 256 ? 256 : mb)) << 20;
-    }();
-    size_t chunk = chunk_bytes_target / ((in_len > out_len ? in_len : out_len) * 32);
-    if (chunk < 4096) chunk = 4096;
-    chunk &= ~(size_t)255;
+    const size_t chunk = staging_chunk_items((in_len > out_len ? in_len : out_len) * 32);
     if (mode == 0 || n < 2 * chunk) {
         int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
         if (rc) return rc;
@@ -652,6 +705,21 @@ int p252_merkle4_path_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t
     for (size_t i = 0; i < n * depth; ++i)
         if (positions[i] > 3) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: position outside 0..3");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (depth > 0xffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_path: depth too large");
+    if (depth) {
+        const size_t chunk = staging_chunk_items(64 + depth * 97);
+        if (n >= 2 * chunk) {  // large batch: leaves, sibling blocks and positions stream through the staging lanes
+            const TagArg targ = tag_arg(tag);
+            return staged_run(ctx, n, chunk,
+                              {{reinterpret_cast<const char*>(leaves), nullptr, 32},
+                               {reinterpret_cast<const char*>(siblings), nullptr, depth * 96},
+                               {reinterpret_cast<const char*>(positions), nullptr, depth}},
+                              {{nullptr, reinterpret_cast<char*>(roots), 32}},
+                              [&](const void* const* d_in, void* const* d_out, size_t, size_t cnt, hipStream_t st) {
+                                  return launch_merkle4_path(ctx->d_tab, targ, d_in[0], d_in[1], d_in[2], (unsigned)depth, d_out[0], cnt, st);
+                              });
+        }
+    }
     const size_t leaf_b = n * 32, sib_b = n * depth * 96, pos_b = (n * depth + 15) & ~(size_t)15;
     int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, leaf_b + sib_b + pos_b + 16);
     if (rc) return rc;
@@ -743,6 +811,27 @@ static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t t
     if (!tag || !in || !secrets || !nonces || !out || (decrypt && !ok))
         return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: NULL buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const size_t in_stride = (decrypt ? len + 1 : len) * 32, out_stride = (decrypt ? len : len + 1) * 32;
+        const size_t chunk = staging_chunk_items(in_stride + out_stride + 96);
+        if (n >= 2 * chunk && len < 0x1ffffff0u) {  // large batch: through the staging lanes, chunk by chunk
+            // upload the call table first (crypt_device does that on its first launch); a one-item launch is the cheapest way
+            std::vector<HostSpan> ins = {{reinterpret_cast<const char*>(in), nullptr, in_stride},
+                                         {reinterpret_cast<const char*>(secrets), nullptr, 64},
+                                         {reinterpret_cast<const char*>(nonces), nullptr, 32}};
+            std::vector<HostSpan> outs = {{nullptr, reinterpret_cast<char*>(out), out_stride}};
+            if (decrypt) outs.push_back({nullptr, reinterpret_cast<char*>(ok), 1});
+            std::mutex mu;
+            return staged_run(ctx, n, chunk, ins, outs,
+                              [&](const void* const* d_in, void* const* d_out, size_t, size_t cnt, hipStream_t st) {
+                                  // crypt_device validates, (re)uploads the program when (variant, len) changed — serialised — and launches
+                                  std::lock_guard<std::mutex> lk(mu);
+                                  const int rc2 = crypt_device(ctx, variant, decrypt, tag, d_in[0], d_in[1], d_in[2], len, d_out[0],
+                                                               decrypt ? d_out[1] : nullptr, cnt, st);
+                                  return rc2 == P252_OK ? hipSuccess : hipErrorUnknown;
+                              });
+        }
+    }
     const size_t in_b = n * (decrypt ? len + 1 : len) * 32, out_b = n * (decrypt ? len : len + 1) * 32;
     const size_t sec_b = n * 64, non_b = n * 32, ok_b = (n + 15) & ~(size_t)15;
     int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_b + sec_b + non_b);

@@ -98,3 +98,42 @@ def test_tree_from_pageable_host_leaves_streams_the_first_level(gpu_ctx, oracle_
     r2, l2 = gpu_ctx.merkle2_tree(tag2, lv, want_levels=True)
     o2 = oracle_mod.merkle2_tree(tag2, lv, want_levels=True)
     assert np.array_equal(r2, o2[0]) and np.array_equal(l2, o2[1])
+
+
+def test_other_host_entry_points_stream_large_batches(gpu_ctx, oracle_mod):
+    """p252_permute_batch, p252_merkle4_path_batch, p252_encrypt_batch / p252_decrypt_batch on batches large enough to go
+    through the staging lanes (several chunks, ragged tail): same bytes as the oracle on a sample and as small calls"""
+    import poseidon252_amd as P
+    from poseidon252_amd.encryption import decrypt_batch, encrypt_batch, encryption_tag
+    from poseidon252_amd.merkle import merkle4_path_roots
+    # permutations: 160 B in / out per item, chunks of 52,224 items
+    n = 3 * 52224 + 1234
+    st = oracle_mod.fill_random(0x9e1, 5 * n).reshape(n, 5, 4)
+    got = gpu_ctx.permute_batch(st)
+    idx = np.concatenate([np.arange(0, n, 7919), [52223, 52224, n - 1]])
+    assert np.array_equal(got[idx], oracle_mod.permute_batch(st[idx]))
+    assert np.array_equal(got[:1000], gpu_ctx.permute_batch(st[:1000]))
+    # openings of depth 12: leaves + 36 siblings + 12 position bytes per item, chunks of 6,656 items
+    n, depth = 4 * 6656 + 77, 12
+    tag = P.merkle4_tag()
+    leaves = oracle_mod.fill_random(0x9e2, n)
+    sibs = oracle_mod.fill_random(0x9e3, n * depth * 3).reshape(n, depth, 3, 4)
+    pos = np.random.default_rng(5).integers(0, 4, size=(n, depth), dtype=np.uint8)
+    roots = merkle4_path_roots(leaves, sibs, pos, tag=tag, ctx=gpu_ctx)
+    idx = np.concatenate([np.arange(0, n, 997), [6655, 6656, n - 1]])
+    assert np.array_equal(roots[idx], oracle_mod.merkle4_path_batch(tag, leaves[idx], sibs[idx], pos[idx]))
+    # encryption of 2-scalar messages (both variants coincide at len 2) and of 21-scalar messages (STREAM)
+    for ln, n in ((2, 2 * 32768 + 999), (21, 3 * 5376 + 5)):
+        msgs = oracle_mod.fill_random(0x9e4 + ln, n * ln).reshape(n, ln, 4)
+        secrets = oracle_mod.fill_random(0x9e5 + ln, 2 * n).reshape(n, 2, 4)
+        nonces = oracle_mod.fill_random(0x9e6 + ln, n)
+        cph = encrypt_batch(msgs, secrets, nonces, ctx=gpu_ctx)
+        idx = np.concatenate([np.arange(0, n, 1009), [n - 1]])
+        assert np.array_equal(cph[idx], oracle_mod.encrypt_batch(encryption_tag(ln), msgs[idx], secrets[idx], nonces[idx]))
+        bad = cph.copy()
+        bad[::5000, 0, 0] ^= np.uint64(1)
+        dec, ok = decrypt_batch(bad, secrets, nonces, ctx=gpu_ctx)
+        assert not ok[::5000].any() and ok.sum() == n - len(ok[::5000])
+        good = np.ones(n, dtype=bool)
+        good[::5000] = False
+        assert np.array_equal(dec[good], msgs[good])
