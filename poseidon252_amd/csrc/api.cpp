@@ -622,8 +622,20 @@ static int merkle_tree_host(p252_ctx* ctx, unsigned arity, const uint64_t tag[4]
         rc = merkle_tree_device(ctx, arity, tag, ctx->d_in, n_leaves, d_root, d_levels, nullptr);
         if (rc) return rc;
     }
-    HIP_TRY(ctx, hipMemcpy(root, d_root, 32, hipMemcpyDeviceToHost));
-    if (levels && lvl_bytes) HIP_TRY(ctx, hipMemcpy(levels, d_levels, lvl_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(root, d_root, 32, hipMemcpyDeviceToHost));  // (also orders the download below behind the build)
+    if (levels && lvl_bytes) {
+        const size_t n_sc = lvl_bytes / 32, chunk = staging_chunk_items(32);
+        if (n_sc >= 2 * chunk && !is_pinned(levels)) {
+            // all levels of a big tree (171 MiB at 2^24 leaves) into pageable memory: chunk by chunk through the staging lanes
+            rc = staged_run(ctx, n_sc, chunk, {}, {{nullptr, reinterpret_cast<char*>(levels), 32}},
+                            [&](const void* const*, void* const* d_out, size_t off, size_t cnt, hipStream_t st) {
+                                return hipMemcpyAsync(d_out[0], d_levels + off * 32, cnt * 32, hipMemcpyDeviceToDevice, st);
+                            });
+            if (rc) return rc;
+        } else {
+            HIP_TRY(ctx, hipMemcpy(levels, d_levels, lvl_bytes, hipMemcpyDeviceToHost));
+        }
+    }
     return P252_OK;
 }
 
