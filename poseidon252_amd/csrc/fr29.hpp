@@ -11,7 +11,7 @@
 // instructions at all, and is Montgomery-reduced once.
 //
 // Representation ("E29"): value V = sum d[i] * 2^(29 i), d[0..7] in [0, 2^29), d[8] signed and small.
-// V is a LAZY residue with |V| < 4p: at the kernels' boundary any integer congruent to x*R (R = 2^256, the
+// V is a LAZY residue (|V| < 2p after a tight reduction, < 5.2p after a wide one — redc_w below): at the kernels' boundary any integer congruent to x*R (R = 2^256, the
 // reference's Montgomery radix); inside a permutation congruent to s*x for a known per-round scale s
 // (tables.hpp).  Signs are tolerated everywhere (columns are signed 64-bit, multiplier constants
 // are balanced digits in [-2^28, 2^28]); only to_mont4() canonicalises to [0, p).
