@@ -16,7 +16,7 @@ HIPCC_FLAGS = [
     "-mllvm", "-pragma-unroll-threshold=1000000",
 ]
 SOURCES = ["kernels.hip", "api.cpp"]
-HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp",
+HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp",
            os.path.join("..", "..", "include", "poseidon252_hip.h")]
 
 
@@ -57,7 +57,7 @@ def build_hosttest(force=False):
     deps = [os.path.join(CSRC, f) for f in ["hosttest.cpp"] + HEADERS]
     if force or _stale(HOSTTEST_LIB, deps):
         # -DP252_TRACK_BOUNDS: the reductions record the largest column / top digit they meet (test_dynamic_bounds)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DP252_TRACK_BOUNDS",
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-DP252_TRACK_BOUNDS",
                                os.path.join(CSRC, "hosttest.cpp"), "-o", HOSTTEST_LIB])
     return HOSTTEST_LIB
 

@@ -1,0 +1,168 @@
+// coop29.hpp — ONE Merkle4 digest computed by a group of 8 lanes: the low-latency build of the permutation.
+//
+// Why: a permutation is ~80 k dependent instructions for the lane that runs it, so a launch of at most one wave per SIMD
+// (a tree's levels of <= 65,536 nodes, small batches) takes 0.165 ms whatever its size.  Such launches
+// leave most lanes of the chip idle; this schedule spends them on the permutation's own coarse parallelism — whole field
+// products, never parts of one (splitting a product over lanes was priced in §3.6: 1.2x) :
+//   full rounds   the five S-boxes of a round run on five lanes (lane i holds state element i); the integer MDS layer
+//                 gathers the five outputs and every lane forms its own row      3 sequential products instead of 15
+//   partial phase W_q = x^5 G_q: the even lane of a pair squares twice (x^2, x^4) while the odd lane computes x G_q,
+//                 one exchange, then both form x^4 * (x G_q) — the same bits on both, so every lane carries the
+//                 complete history and the recurrence needs no exchange          3 sequential products instead of 4
+//   exit          the four exit rows run on four lanes (and land where the next full round wants them)   1 instead of 4
+// Sequential generic products per digest: 8 x 3 + 3 + 60 x 3 + 1 + 1 = 209 (one lane: 365).  Everything else — the
+// entry rows, the recurrence — is computed redundantly by all lanes, uniformly, with the constants in SGPRs as before.
+//
+// All arithmetic is the single-lane code of fr29.hpp / hades29.hpp (same tables, same reductions); the values are the
+// same residues, in places in a different lazy representative, and the result is canonicalised by to_mont4 as always.
+//
+// Comm: lane() = index within the group (0..7); get(e, src) = the element held by lane `src` of my group (src may differ
+// from lane to lane); swap1(e) = the element held by lane ^ 1.  Device: ds_bpermute_b32 / DPP quad_perm (kernels.hip);
+// host (unit tests): eight threads and a barrier (hosttest.cpp).
+#pragma once
+#include "hades29.hpp"
+
+namespace p252 {
+
+constexpr int COOP_LANES = 8;
+
+// x^5 G / R'^5 on a pair of lanes (odd = true for the odd lane).  g = the nine digits of G_q (wave-uniform).
+template <class Comm, class TP>
+P252_HD E29 coop_sbox_g(const E29& u, TP g, bool odd, const RK& K, Comm& cm) {
+    // (G is read unconditionally — nine scalar loads for the wave — and then selected per lane: a load inside the
+    // conditional expression cannot be speculated and becomes nine exec-masked branches)
+    int32_t gd[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) gd[k] = g[k];
+    E29 op;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) op.d[k] = odd ? gd[k] : u.d[k];
+    A29 t;
+    acc_zero_w(t, K);
+    acc_mul(t, u, op.d);  // even: u^2 / R'; odd: u G / R'
+    const E29 t1 = redc_w(t, K);
+    acc_zero_w(t, K);
+    acc_sqr(t, t1);  // even: u^4 / R'^3 (odd: unused)
+    const E29 t2 = redc_w(t, K);
+    E29 mine;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) mine.d[k] = odd ? t1.d[k] : t2.d[k];
+    const E29 other = cm.swap1(mine);
+    // even: u^4 * (u G); odd: (u G) * u^4 — the same 81 digit products summed (exactly) into the same columns: identical bits
+    acc_zero_w(t, K);
+    acc_mul(t, mine, other.d);
+    return redc_w(t, K);
+}
+
+template <int QM, class Comm, class TP>
+P252_HD void coop_ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, bool odd, const RK& K, Comm& cm) {
+    Ws[QM] = coop_sbox_g(Us[QM], kg + NL, odd, K, cm);
+    ai_recur<QM>(Us, Ws, ab, kg, K);
+}
+
+// a table entry at a per-lane index, loaded where the source says (see merkle4_digest_coop)
+template <class TP>
+P252_HD int32_t lane_const(TP tab, int index) {
+    return tab[index];
+}
+// "this value is needed here": the load that produces it cannot be sunk below this point (emits no instruction)
+P252_HD void pin_loaded(int32_t& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+}
+
+// my row of the integer MDS layer: sum_m hn[m] xs[m] + kappa, one digit step (hn = my five Hankel entries, in VGPRs)
+P252_HD E29 coop_int_row(const E29 xs[WIDTH], const int32_t hn[WIDTH], const int32_t kap[NL]) {
+    R29 t;
+    row_set_c(t, kap);
+#pragma unroll
+    for (int m = 0; m < WIDTH; ++m) row_mac(t, xs[m], hn[m]);
+    return row_redc1(t);
+}
+
+// The digest of one node: lane i (< 5) passes state element i (the tag, then the four children; lanes 5..7 anything),
+// every lane returns perm(state)[1] at the reference's Montgomery scale (lazy; to_mont4 canonicalises).
+template <class Comm, class TP>
+P252_HD E29 merkle4_digest_coop(const E29& element, TP tab, Comm& cm) {
+    typedef Tab29Layout Lay;
+    constexpr int RF = FULL_ROUNDS / 2;
+    const RK K = make_rk();
+    const int lane = cm.lane();
+    const int row = lane < WIDTH ? lane : WIDTH - 1;  // my state element / my row of the linear layers
+    const bool odd = (lane & 1) != 0;
+    int32_t hn[WIDTH];
+#pragma unroll
+    for (int m = 0; m < WIDTH; ++m) hn[m] = tab[Lay::INT_N + row + m];
+    E29 s = element;
+    {
+        int32_t c0[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) c0[k] = tab[Lay::C_FIRST + row * NL + k];
+        add_c(s, c0);
+    }
+    // Per-lane constants (my row's kappa, my exit row) are vector loads with ~1 us of latency and nothing to overlap it
+    // at their point of use, which is where the optimiser sinks them.  They are fetched one step ahead instead: round
+    // f + 1's kappa as a loop-carried value while round f runs, the exit row before the entry rows, pinned (pin_loaded)
+    // ahead of the 60 partial rounds.
+    int32_t kap[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) kap[k] = lane_const(tab, Lay::AI_KAPPA + row * NL + k);
+    E29 xs[WIDTH];
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+        for (int f = half * RF; f < (half + 1) * RF; ++f) {
+            int32_t kap_next[NL];
+            const int fn = f + 1 < 2 * RF ? f + 1 : f;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) kap_next[k] = lane_const(tab, Lay::AI_KAPPA + (fn * WIDTH + row) * NL + k);
+            const E29 x = sbox_w(s, K);
+#pragma unroll
+            for (int m = 0; m < WIDTH; ++m) xs[m] = cm.get(x, m);
+            if (f != RF - 1 && f != 2 * RF - 1) s = coop_int_row(xs, hn, kap);
+#pragma unroll
+            for (int k = 0; k < NL; ++k) kap[k] = kap_next[k];
+        }
+        if (half == 0) {
+            // my exit row's constants (hidden by the entry and the 60 rounds below)
+            const int er = lane < 4 ? lane : 3;
+            int32_t exn[2 * NL], exfix[NL], exadd[NL];
+#pragma unroll
+            for (int k = 0; k < 2 * NL; ++k) exn[k] = lane_const(tab, Lay::AI_EX_N + er * 2 * NL + k);
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                exfix[k] = lane_const(tab, Lay::AI_EX_FIX + er * NL + k);
+                exadd[k] = lane_const(tab, Lay::AI_EX_ADD + er * NL + k);
+            }
+            E29 Us[HIST], Ws[HIST];
+            arma_entry(xs, Us, Ws, tab, K);  // redundantly on every lane: 3 products, and no exchange afterwards
+#pragma unroll
+            for (int k = 0; k < 2 * NL; ++k) pin_loaded(exn[k]);
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                pin_loaded(exfix[k]);
+                pin_loaded(exadd[k]);
+            }
+#pragma unroll 1
+            for (int it = 0; it < PARTIAL_ROUNDS / HIST; ++it) {
+                const TP kg = tab + Lay::AI_KG + it * HIST * 2 * NL;
+                coop_ai_round<1>(Us, Ws, tab + Lay::AI_AB, kg, odd, K, cm);
+                coop_ai_round<2>(Us, Ws, tab + Lay::AI_AB, kg + 2 * NL, odd, K, cm);
+                coop_ai_round<3>(Us, Ws, tab + Lay::AI_AB, kg + 4 * NL, odd, K, cm);
+                coop_ai_round<4>(Us, Ws, tab + Lay::AI_AB, kg + 6 * NL, odd, K, cm);
+                coop_ai_round<0>(Us, Ws, tab + Lay::AI_AB, kg + 8 * NL, odd, K, cm);
+            }
+            const E29* const us[4] = {&Us[3], &Us[4], &Us[0], &Us[1]};
+            const E29* const ws[4] = {&Ws[2], &Ws[3], &Ws[4], &Ws[0]};
+            const E29 r = exit_row(us, ws, exn, exfix, exadd, K);
+#pragma unroll
+            for (int k = 0; k < NL; ++k) s.d[k] = lane < 4 ? r.d[k] : Us[1].d[k];  // lanes 0..3: my row; lane 4: U_61
+        }
+    }
+    // the last linear layer: only row 1 is squeezed — every lane forms it (uniform constants), then the scale F
+    const E29 d = int_row(xs, tab + Lay::INT_N + 1, tab + Lay::AI_KAPPA + ((2 * RF - 1) * WIDTH + 1) * NL);
+    return mul_c(d, tab + Lay::AI_F);
+}
+
+}  // namespace p252

@@ -62,8 +62,8 @@ struct BoundTrack {
     int32_t max_top = 0;   // reduction outputs (multiplicands of generic products)
     int32_t max_top1 = 0;  // W_0 = 28 X_4 + const (multiplicand of one-digit products only)
 };
-inline BoundTrack& bound_track() {
-    static BoundTrack b;
+inline BoundTrack& bound_track() {  // per thread (the cooperative digest's host test runs eight of them and merges)
+    static thread_local BoundTrack b;
     return b;
 }
 inline void trk_col(int64_t v) {

@@ -148,9 +148,8 @@ P252_HD void hades_permute_int(E29 s[WIDTH], TP tab) {
 // ab = A_1..A_4, B_0..B_4 (ints); kg = K_{q+1}[9], G_q[9].  U_{q+1} overwrites U_{q-4}, W_q overwrites W_{q-5}.
 constexpr int HIST = 5;
 template <int QM /* q mod HIST */, class TP>
-P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, const RK& K) {
+P252_HD void ai_recur(E29 Us[HIST], const E29 Ws[HIST], TP ab, TP kg, const RK& K) {  // U_{q+1} from the rings (W_q included)
     constexpr int Q = QM + HIST;  // keeps (Q - j) % HIST non-negative
-    Ws[Q % HIST] = mul_c_w(sbox_w(Us[Q % HIST], K), kg + NL, K);
     int64_t c[NL + 5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) c[k] = K.bias;  // the five columns that get a (wide) digit step, fr29.hpp
@@ -185,6 +184,11 @@ P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, const RK& K) {
     r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 4] + carry));
     P252_TRK_TOP(r.d[NL - 1]);
     Us[(Q + 1) % HIST] = r;
+}
+template <int QM /* q mod HIST */, class TP>
+P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, const RK& K) {
+    Ws[QM] = mul_c_w(sbox_w(Us[QM], K), kg + NL, K);
+    ai_recur<QM>(Us, Ws, ab, kg, K);
 }
 
 // Exit row i: lanes 0..3 of the state after round 60 from (U_58..U_61, W_57..W_60).  The coefficients are rationals
@@ -286,6 +290,28 @@ P252_HD E29 small_mul_add(const E29& x, int32_t m, TP add) {
     return r;
 }
 
+// The entry of the partial phase from the five S-box outputs x of full round 3: U_1 (the integer row of lane 4) and the
+// virtual history U_0, U_-1, U_-2, W_0 (older W = 0), placed in the rings where round q = 1 expects them.
+template <class TP>
+P252_HD void arma_entry(const E29 x[WIDTH], E29 Us[HIST], E29 Ws[HIST], TP tab, const RK& K) {
+    typedef Tab29Layout Lay;
+    constexpr int RF = FULL_ROUNDS / 2;
+    Us[1] = int_row(x, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + ((RF - 1) * WIDTH + 4) * NL);  // U_1
+    sched_fence();
+    // U_0, U_-1, U_-2: virtual
+    Us[0] = entry_row<1>(x, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD, K);
+    sched_fence();
+    Us[HIST - 1] = entry_row<1>(x, tab + Lay::AI_ENT_N + NL, tab + Lay::AI_ENT_FIX + NL, tab + Lay::AI_ENT_ADD + NL, K);
+    sched_fence();
+    Us[HIST - 2] = entry_row<2>(x, tab + Lay::AI_ENT_N + 2 * NL, tab + Lay::AI_ENT_FIX + 2 * NL, tab + Lay::AI_ENT_ADD + 2 * NL, K);
+    sched_fence();
+    Us[2] = e29_zero();  // (free slot)
+    // W_0: virtual, = the lane-4 S-box output at the W scale (28 = 13 D / K); W_-1, W_-2, W_-3 = 0
+    Ws[0] = small_mul_add(x[4], ENTRY_W0_INT, tab + Lay::AI_ENT_ADD + 3 * NL);
+#pragma unroll
+    for (int i = 1; i < HIST; ++i) Ws[i] = e29_zero();
+}
+
 // Loop nest: two halves, each = four full rounds (one copy of that body in the instruction stream), the first half
 // followed by the partial phase: 12 iterations of HIST = 5 ARMA rounds in a loop of their own (its loop-carried
 // values are exactly the two history rings), then the exit rows (exit_row).  Full round 3 is the entry: its linear
@@ -329,20 +355,7 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
         if (half == 0) {
             // (the history rings are defined here, after the loop above, so that they are not carried through it)
             E29 Us[HIST], Ws[HIST];
-            Us[1] = int_row(s, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + ((RF - 1) * WIDTH + 4) * NL);  // U_1
-            sched_fence();
-            // U_0, U_-1, U_-2: virtual
-            Us[0] = entry_row<1>(s, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD, K);
-            sched_fence();
-            Us[HIST - 1] = entry_row<1>(s, tab + Lay::AI_ENT_N + NL, tab + Lay::AI_ENT_FIX + NL, tab + Lay::AI_ENT_ADD + NL, K);
-            sched_fence();
-            Us[HIST - 2] = entry_row<2>(s, tab + Lay::AI_ENT_N + 2 * NL, tab + Lay::AI_ENT_FIX + 2 * NL, tab + Lay::AI_ENT_ADD + 2 * NL, K);
-            sched_fence();
-            Us[2] = e29_zero();  // (free slot)
-            // W_0: virtual, = the lane-4 S-box output at the W scale (28 = 13 D / K); W_-1, W_-2, W_-3 = 0
-            Ws[0] = small_mul_add(s[4], ENTRY_W0_INT, tab + Lay::AI_ENT_ADD + 3 * NL);
-#pragma unroll
-            for (int i = 1; i < HIST; ++i) Ws[i] = e29_zero();
+            arma_entry(s, Us, Ws, tab, K);
 #pragma unroll 1
             for (int it = 0; it < PARTIAL_ROUNDS / HIST; ++it) {  // rounds q = 5 it + 1 .. 5 it + 5
                 const TP kg = tab + Lay::AI_KG + it * HIST * 2 * NL;

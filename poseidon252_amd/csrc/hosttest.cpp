@@ -7,6 +7,12 @@
 #include <cstring>
 #include <vector>
 
+#include <pthread.h>
+
+#include <mutex>
+#include <thread>
+
+#include "coop29.hpp"
 #include "hades29.hpp"
 #include "_gen/assets.inc"
 
@@ -128,6 +134,74 @@ void ht_merkle4_digest29(const uint64_t* tag, const uint64_t* children, uint64_t
         for (int k = 0; k < 4; ++k) s[1 + k] = from_mont4(reinterpret_cast<const uint32_t*>(children + (i * 4 + k) * 4));
         hades_permute<0x02u, true>(s, tab);
         to_mont4(s[1], reinterpret_cast<uint32_t*>(out + i * 4));
+    }
+}
+
+// the cooperative digest (coop29.hpp) with its eight lanes played by eight threads: Comm = shared slots + a barrier.
+// Exactly the code k_merkle4_coop runs; the device replaces the exchange by ds_bpermute / DPP.
+namespace {
+struct HostGroup {
+    pthread_barrier_t bar;
+    E29 slot[COOP_LANES];
+    std::mutex mu;
+#if defined(P252_TRACK_BOUNDS)
+    BoundTrack merged;
+#endif
+};
+struct HostComm {
+    HostGroup* g;
+    int j;
+    int lane() const { return j; }
+    E29 get(const E29& v, int src) {
+        g->slot[j] = v;
+        pthread_barrier_wait(&g->bar);
+        const E29 r = g->slot[src];
+        pthread_barrier_wait(&g->bar);
+        return r;
+    }
+    E29 swap1(const E29& v) { return get(v, j ^ 1); }
+};
+}  // namespace
+
+void ht_merkle4_digest_coop(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n) {
+    const int32_t* tab = tab29().data();
+    HostGroup g;
+    pthread_barrier_init(&g.bar, nullptr, COOP_LANES);
+    std::vector<std::thread> th;
+    std::vector<uint64_t> res((size_t)COOP_LANES * n * 4);
+    for (int j = 0; j < COOP_LANES; ++j)
+        th.emplace_back([&, j] {
+            HostComm cm{&g, j};
+            for (size_t i = 0; i < n; ++i) {
+                const int el = j < WIDTH ? j : WIDTH - 1;
+                const E29 mine = from_mont4(reinterpret_cast<const uint32_t*>(el == 0 ? tag : children + (i * 4 + el - 1) * 4));
+                const E29 r = merkle4_digest_coop(mine, tab, cm);
+                to_mont4(r, reinterpret_cast<uint32_t*>(res.data() + ((size_t)j * n + i) * 4));
+            }
+#if defined(P252_TRACK_BOUNDS)
+            std::lock_guard<std::mutex> lk(g.mu);
+            const BoundTrack& b = bound_track();
+            if (b.max_col > g.merged.max_col) g.merged.max_col = b.max_col;
+            if (b.max_top > g.merged.max_top) g.merged.max_top = b.max_top;
+            if (b.max_top1 > g.merged.max_top1) g.merged.max_top1 = b.max_top1;
+#endif
+        });
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&g.bar);
+#if defined(P252_TRACK_BOUNDS)
+    BoundTrack& b = bound_track();
+    if (g.merged.max_col > b.max_col) b.max_col = g.merged.max_col;
+    if (g.merged.max_top > b.max_top) b.max_top = g.merged.max_top;
+    if (g.merged.max_top1 > b.max_top1) b.max_top1 = g.merged.max_top1;
+#endif
+    // every lane must hold the same digest; lane 0's is returned, a disagreement is reported as all-ones
+    for (size_t i = 0; i < n; ++i) {
+        bool same = true;
+        for (int j = 1; j < COOP_LANES; ++j) same = same && std::memcmp(&res[((size_t)j * n + i) * 4], &res[i * 4], 32) == 0;
+        if (same)
+            std::memcpy(out + i * 4, &res[i * 4], 32);
+        else
+            std::memset(out + i * 4, 0xff, 32);
     }
 }
 

@@ -8,6 +8,9 @@
 // whole stream is < 20 GB/s (0.3 % of HBM peak), so no staging/transposition is warranted.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
+#include "coop29.hpp"
 #include "hades29.hpp"
 #include "kernels.h"
 
@@ -123,6 +126,52 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_pad(const int32_t* __res
     }
     hades_permute<0x02u, true>(s, tab);
     store_scalar(out + idx, s[1]);
+}
+
+// ---- the low-latency digest: ONE node per group of 8 lanes (coop29.hpp) — for launches that cannot fill the chip
+// anyway (a tree's levels of <= 8,192 nodes, small batches).  209 sequential field products per digest instead of 365:
+// a lone wave finishes in ~0.10 ms instead of 0.165.  Exchange: the five S-box outputs of a full round travel by
+// ds_bpermute_b32 (the LDS crossbar, no LDS memory: 45 per round, issued back to back), the one element a partial
+// round swaps inside a lane pair by DPP quad_perm [1,0,3,2] on v_mov_b32 (VALU, no wait).  `lanes` >= 8 n: as in
+// k_merkle4_pad, group g hashes node g mod n so that a large tree's narrow levels keep every SIMD busy. ----
+struct WaveComm {
+    int j;      // my index within the group
+    int base4;  // ds_bpermute byte address of my group's lane 0 (within the wave)
+    __device__ __forceinline__ int lane() const { return j; }
+    __device__ __forceinline__ E29 get(const E29& v, int src) const {
+        E29 r;
+        const int addr = base4 + 4 * src;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) r.d[k] = __builtin_amdgcn_ds_bpermute(addr, v.d[k]);
+        return r;
+    }
+    __device__ __forceinline__ E29 swap1(const E29& v) const {
+        E29 r;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) r.d[k] = __builtin_amdgcn_mov_dpp(v.d[k], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+        return r;
+    }
+};
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __restrict__ tab, TagArg tag,
+                                                             const Scalar32* __restrict__ children,
+                                                             size_t n_children, Scalar32* __restrict__ out,
+                                                             size_t n, unsigned arity, size_t lanes) {
+    const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (lane >= lanes) return;  // (lanes is a multiple of 8: whole groups only)
+    const size_t idx = (lane / COOP_LANES) % n;
+    const int j = (int)(threadIdx.x & (COOP_LANES - 1));
+    const int el = j < WIDTH ? j : WIDTH - 1;  // the state element this lane brings: 0 = tag, 1..4 = children
+    E29 mine = from_mont4(tag.w);
+    {
+        const size_t c = idx * arity + (size_t)(el > 0 ? el - 1 : 0);
+        const bool present = el > 0 && (unsigned)(el - 1) < arity && c < n_children;
+        const E29 child = present ? load_scalar(children + c) : e29_zero();
+#pragma unroll
+        for (int k = 0; k < NL; ++k) mine.d[k] = el > 0 ? child.d[k] : mine.d[k];
+    }
+    WaveComm cm{j, (int)(((threadIdx.x & 63u) & ~(unsigned)(COOP_LANES - 1)) * 4u)};
+    const E29 r = merkle4_digest_coop(mine, tab, cm);
+    if (j == 0) store_scalar(out + idx, r);
 }
 
 // ---- generic sponge: n messages, same (in_len, out_len).  dusk-safe mechanics:
@@ -330,6 +379,18 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
                           void* out, size_t n, hipStream_t st, unsigned arity, size_t pad_lanes) {
     if (n == 0) return hipSuccess;
+    // launches of at most one wave per SIMD with 8 lanes per node: the cooperative low-latency build
+    static const size_t coop_max = [] {
+        const char* e = std::getenv("P252_COOP_MAX_NODES");
+        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)8192;
+    }();
+    if (n <= coop_max) {
+        const size_t want = n * COOP_LANES;
+        const size_t lanes = want < pad_lanes ? pad_lanes : want;
+        hipLaunchKernelGGL(k_merkle4_coop, dim3(grid_for(lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, lanes);
+        return hipGetLastError();
+    }
     if (n < pad_lanes) {
         hipLaunchKernelGGL(k_merkle4_pad, dim3(grid_for(pad_lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
                            static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, pad_lanes);
