@@ -444,18 +444,25 @@ def main():
         achieved_mac = per_gpu_rate * MACS_PER_PERM_REFERENCE
         hbm_gbps = per_gpu_rate * BYTES_PER_PERM[wl] / 1e9
         kern = KERNEL_OF[wl]
+        lanes_per_perm = 1
+        coop_max = int(os.environ.get("P252_COOP_MAX_NODES", "16384"))
+        if wl == "merkle4_digests" and 8192 < perms_per_step <= min(coop_max, 16384):
+            kern, lanes_per_perm = "k_merkle4_coop<4>", 4
+        elif wl == "merkle4_digests" and perms_per_step <= min(coop_max, 8192):
+            # launches this small run the cooperative low-latency kernel: eight lanes per digest (csrc/coop29.hpp)
+            kern, lanes_per_perm = "k_merkle4_coop<8>", 8
         isa = isa_counts(kern)
         executed = issue = None
         if isa:
-            mac_rate = per_gpu_rate * isa["v_mad_i64_i32"]
-            executed = {"macs_per_perm": isa["v_mad_i64_i32"], "achieved": mac_rate / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12,
+            mac_rate = per_gpu_rate * lanes_per_perm * isa["v_mad_i64_i32"]
+            executed = {"macs_per_perm": isa["v_mad_i64_i32"] * lanes_per_perm, "achieved": mac_rate / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12,
                         "frac": mac_rate / PEAK_INT32_MAC_PER_S, "unit": "TMAC/s", "source": isa["source"],
                         "frac_of_measured_mad_stream": mac_rate / (MEASURED_MAD_STREAM_WAVE_INST_PER_S * 64),
                         "note": "the fraction of the hardware: multiply-adds actually issued (counted in the ISA) / (1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes)"}
             # every VALU instruction priced at its issue cost (4 cycles for multiply-adds, 64-bit adds / shifts and VOP3
             # 3-operand forms, 2 for plain 32-bit ops — profiles/r02_valu_rates_gfx950.txt): share of all SIMD cycles
-            cyc = per_gpu_rate / 64.0 * isa["valu_issue_cycles"]
-            issue = {"valu_insts_per_perm": isa["valu_total"], "issue_cycles_per_perm": isa["valu_issue_cycles"],
+            cyc = per_gpu_rate * lanes_per_perm / 64.0 * isa["valu_issue_cycles"]
+            issue = {"valu_insts_per_perm": isa["valu_total"], "lanes_per_perm": lanes_per_perm, "issue_cycles_per_perm": isa["valu_issue_cycles"],
                      "frac": cyc / (SIMDS * NOMINAL_CLOCK_HZ), "pmc": pmc_valu(kern),
                      "note": "SIMD cycles spent issuing VALU work under the 4-/2-cycle model / all SIMD cycles at 2.4 GHz"}
         roofline = {

@@ -1,20 +1,24 @@
 #!/bin/bash
-# round 2, GPU call 10: the cooperative low-latency digest kernel (k_merkle4_coop) — parity, small-batch latency, tree
+# round 2, GPU call 10: the cooperative low-latency digest kernels (k_merkle4_coop<8|4>) — parity, small-batch latency, tree
 cd "${GRAFT_REPO_ROOT:-.}"
 ROOT=$(pwd)
 O=$ROOT/gpurun_out/r02j; mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_coop.py tests/test_gpu_parity.py -m gpu -x -q > $O/pytest_coop.txt 2>&1; echo "pytest rc=$?"; tail -6 $O/pytest_coop.txt
-for l in 6 10 12 13; do
-  for coop in 8192 0; do
+for l in 12 13; do
+  for coop in 16384 0; do
     P252_COOP_MAX_NODES=$coop python bench.py --log2n $l --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_small_${l}_coop$coop.json 2>$O/err.txt || tail -3 $O/err.txt
   done
 done
-# 2^14 nodes: two waves per SIMD of the cooperative kernel against one wave of the one-lane kernel
-for coop in 16384 0; do P252_COOP_MAX_NODES=$coop python bench.py --log2n 14 --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_small_14_coop$coop.json 2>/dev/null; done
+# 2^14 nodes: the 4-lane cooperative kernel against one wave of the one-lane kernel
+for coop in 16384 8192; do P252_COOP_MAX_NODES=$coop python bench.py --log2n 14 --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_small_14_coop$coop.json 2>/dev/null; done
+# two and four waves per SIMD: the 2-wave build (k_merkle4_lat) against the 3-wave build (k_merkle4)
+for l in 17 18; do for m in 0x16 0x2; do
+  P252_LAT_WAVES=$m python bench.py --log2n $l --steps 200 --warmup 30 --no-cpu-baseline > $O/bench_w_${l}_lat$m.json 2>/dev/null
+done; done
 for rep in 1 2; do
-for coop in 8192 16384 0; do
-  P252_COOP_MAX_NODES=$coop python bench.py --workload tree --no-cpu-baseline > $O/bench_tree_coop${coop}_$rep.json 2>/dev/null
+for v in "16384 0x16" "8192 0x16" "16384 0x2" "0 0x2"; do set -- $v
+  P252_COOP_MAX_NODES=$1 P252_LAT_WAVES=$2 python bench.py --workload tree --no-cpu-baseline > $O/bench_tree_coop$1_lat$2_$rep.json 2>/dev/null
 done; done
 python bench.py --no-cpu-baseline > $O/bench.json 2>/dev/null
 python - <<PY

@@ -16,15 +16,18 @@
 // All arithmetic is the single-lane code of fr29.hpp / hades29.hpp (same tables, same reductions); the values are the
 // same residues, in places in a different lazy representative, and the result is canonicalised by to_mont4 as always.
 //
-// Comm: lane() = index within the group (0..7); get(e, src) = the element held by lane `src` of my group (src may differ
-// from lane to lane); swap1(e) = the element held by lane ^ 1.  Device: ds_bpermute_b32 / DPP quad_perm (kernels.hip);
-// host (unit tests): eight threads and a barrier (hosttest.cpp).
+// Two group sizes.  LANES = 8 as described (launches of <= 8,192 nodes at one wave per SIMD).  LANES = 4 (<= 16,384
+// nodes): lanes 0..3 hold state elements 0..3 and EVERY lane carries element 4 as well, so a full round is two S-boxes
+// deep (mine, then element 4 redundantly) and two rows (mine, row 4): 8 x 6 + 3 + 60 x 3 + 1 + 1 = 233 sequential products.
+//
+// Comm: lane() = index within the group; get<M>(e) = the element held by lane M of my group; swap1(e) = the element held
+// by lane ^ 1.  Device (kernels.hip): 8 lanes — ds_bpermute_b32; 4 lanes — DPP quad_perm broadcast; swap1 — DPP
+// quad_perm [1,0,3,2].  Host (unit tests): one thread per lane and a barrier (hosttest.cpp).
 #pragma once
 #include "hades29.hpp"
 
 namespace p252 {
 
-constexpr int COOP_LANES = 8;
 
 // x^5 G / R'^5 on a pair of lanes (odd = true for the odd lane).  g = the nine digits of G_q (wave-uniform).
 template <class Comm, class TP>
@@ -81,25 +84,29 @@ P252_HD E29 coop_int_row(const E29 xs[WIDTH], const int32_t hn[WIDTH], const int
     return row_redc1(t);
 }
 
-// The digest of one node: lane i (< 5) passes state element i (the tag, then the four children; lanes 5..7 anything),
-// every lane returns perm(state)[1] at the reference's Montgomery scale (lazy; to_mont4 canonicalises).
-template <class Comm, class TP>
-P252_HD E29 merkle4_digest_coop(const E29& element, TP tab, Comm& cm) {
+// The digest of one node.  LANES = 8: lane i (< 5) passes state element i (the tag, then the four children; lanes 5..7
+// anything) and `element4` is ignored.  LANES = 4: lane i passes element i and every lane passes element 4 as well.
+// Every lane returns perm(state)[1] at the reference's Montgomery scale (lazy; to_mont4 canonicalises).
+template <int LANES, class Comm, class TP>
+P252_HD E29 merkle4_digest_coop(const E29& element, const E29& element4, TP tab, Comm& cm) {
+    static_assert(LANES == 8 || LANES == 4, "group sizes: 8 (five S-boxes side by side) or 4 (element 4 on every lane)");
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
+    constexpr int OWN = LANES == 8 ? WIDTH : 4;  // state elements that live on a lane of their own
     const RK K = make_rk();
     const int lane = cm.lane();
-    const int row = lane < WIDTH ? lane : WIDTH - 1;  // my state element / my row of the linear layers
+    const int row = lane < OWN ? lane : OWN - 1;  // my state element / my row of the linear layers
     const bool odd = (lane & 1) != 0;
     int32_t hn[WIDTH];
 #pragma unroll
     for (int m = 0; m < WIDTH; ++m) hn[m] = tab[Lay::INT_N + row + m];
-    E29 s = element;
+    E29 s = element, s4 = element4;
     {
         int32_t c0[NL];
 #pragma unroll
         for (int k = 0; k < NL; ++k) c0[k] = tab[Lay::C_FIRST + row * NL + k];
         add_c(s, c0);
+        if (LANES == 4) add_c(s4, tab + Lay::C_FIRST + 4 * NL);
     }
     // Per-lane constants (my row's kappa, my exit row) are vector loads with ~1 us of latency and nothing to overlap it
     // at their point of use, which is where the optimiser sinks them.  They are fetched one step ahead instead: round
@@ -118,9 +125,18 @@ P252_HD E29 merkle4_digest_coop(const E29& element, TP tab, Comm& cm) {
 #pragma unroll
             for (int k = 0; k < NL; ++k) kap_next[k] = lane_const(tab, Lay::AI_KAPPA + (fn * WIDTH + row) * NL + k);
             const E29 x = sbox_w(s, K);
-#pragma unroll
-            for (int m = 0; m < WIDTH; ++m) xs[m] = cm.get(x, m);
-            if (f != RF - 1 && f != 2 * RF - 1) s = coop_int_row(xs, hn, kap);
+            xs[0] = cm.template get<0>(x);
+            xs[1] = cm.template get<1>(x);
+            xs[2] = cm.template get<2>(x);
+            xs[3] = cm.template get<3>(x);
+            if (LANES == 8)
+                xs[4] = cm.template get<4>(x);
+            else
+                xs[4] = sbox_w(s4, K);
+            if (f != RF - 1 && f != 2 * RF - 1) {
+                s = coop_int_row(xs, hn, kap);
+                if (LANES == 4) s4 = int_row(xs, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + (f * WIDTH + 4) * NL);
+            }
 #pragma unroll
             for (int k = 0; k < NL; ++k) kap[k] = kap_next[k];
         }
@@ -158,6 +174,7 @@ P252_HD E29 merkle4_digest_coop(const E29& element, TP tab, Comm& cm) {
             const E29 r = exit_row(us, ws, exn, exfix, exadd, K);
 #pragma unroll
             for (int k = 0; k < NL; ++k) s.d[k] = lane < 4 ? r.d[k] : Us[1].d[k];  // lanes 0..3: my row; lane 4: U_61
+            s4 = Us[1];
         }
     }
     // the last linear layer: only row 1 is squeezed — every lane forms it (uniform constants), then the scale F

@@ -139,10 +139,11 @@ void ht_merkle4_digest29(const uint64_t* tag, const uint64_t* children, uint64_t
 
 // the cooperative digest (coop29.hpp) with its eight lanes played by eight threads: Comm = shared slots + a barrier.
 // Exactly the code k_merkle4_coop runs; the device replaces the exchange by ds_bpermute / DPP.
+extern "C++" {
 namespace {
 struct HostGroup {
     pthread_barrier_t bar;
-    E29 slot[COOP_LANES];
+    E29 slot[8];
     std::mutex mu;
 #if defined(P252_TRACK_BOUNDS)
     BoundTrack merged;
@@ -152,30 +153,35 @@ struct HostComm {
     HostGroup* g;
     int j;
     int lane() const { return j; }
-    E29 get(const E29& v, int src) {
+    E29 exchange(const E29& v, int src) {
         g->slot[j] = v;
         pthread_barrier_wait(&g->bar);
         const E29 r = g->slot[src];
         pthread_barrier_wait(&g->bar);
         return r;
     }
-    E29 swap1(const E29& v) { return get(v, j ^ 1); }
+    template <int M>
+    E29 get(const E29& v) {
+        return exchange(v, M);
+    }
+    E29 swap1(const E29& v) { return exchange(v, j ^ 1); }
 };
-}  // namespace
 
-void ht_merkle4_digest_coop(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n) {
+template <int LANES>
+void digest_coop_threads(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n) {
     const int32_t* tab = tab29().data();
     HostGroup g;
-    pthread_barrier_init(&g.bar, nullptr, COOP_LANES);
+    pthread_barrier_init(&g.bar, nullptr, LANES);
     std::vector<std::thread> th;
-    std::vector<uint64_t> res((size_t)COOP_LANES * n * 4);
-    for (int j = 0; j < COOP_LANES; ++j)
+    std::vector<uint64_t> res((size_t)LANES * n * 4);
+    for (int j = 0; j < LANES; ++j)
         th.emplace_back([&, j] {
             HostComm cm{&g, j};
             for (size_t i = 0; i < n; ++i) {
-                const int el = j < WIDTH ? j : WIDTH - 1;
+                const int el = LANES == 8 ? (j < WIDTH ? j : WIDTH - 1) : j;
                 const E29 mine = from_mont4(reinterpret_cast<const uint32_t*>(el == 0 ? tag : children + (i * 4 + el - 1) * 4));
-                const E29 r = merkle4_digest_coop(mine, tab, cm);
+                const E29 last = from_mont4(reinterpret_cast<const uint32_t*>(children + (i * 4 + 3) * 4));
+                const E29 r = merkle4_digest_coop<LANES>(mine, last, tab, cm);
                 to_mont4(r, reinterpret_cast<uint32_t*>(res.data() + ((size_t)j * n + i) * 4));
             }
 #if defined(P252_TRACK_BOUNDS)
@@ -197,12 +203,25 @@ void ht_merkle4_digest_coop(const uint64_t* tag, const uint64_t* children, uint6
     // every lane must hold the same digest; lane 0's is returned, a disagreement is reported as all-ones
     for (size_t i = 0; i < n; ++i) {
         bool same = true;
-        for (int j = 1; j < COOP_LANES; ++j) same = same && std::memcmp(&res[((size_t)j * n + i) * 4], &res[i * 4], 32) == 0;
+        for (int j = 1; j < LANES; ++j) same = same && std::memcmp(&res[((size_t)j * n + i) * 4], &res[i * 4], 32) == 0;
         if (same)
             std::memcpy(out + i * 4, &res[i * 4], 32);
         else
             std::memset(out + i * 4, 0xff, 32);
     }
+}
+}  // namespace
+}  // extern "C++"
+
+// lanes = 8 or 4 (the two group sizes of coop29.hpp); returns 0, or -1 for any other value
+int ht_merkle4_digest_coop(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n, int lanes) {
+    if (lanes == 8)
+        digest_coop_threads<8>(tag, children, out, n);
+    else if (lanes == 4)
+        digest_coop_threads<4>(tag, children, out, n);
+    else
+        return -1;
+    return 0;
 }
 
 // Static worst-case |column| of every lazy accumulation in the schedules, assuming state digits

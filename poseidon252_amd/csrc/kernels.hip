@@ -128,19 +128,21 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_pad(const int32_t* __res
     store_scalar(out + idx, s[1]);
 }
 
-// ---- the low-latency digest: ONE node per group of 8 lanes (coop29.hpp) — for launches that cannot fill the chip
-// anyway (a tree's levels of <= 8,192 nodes, small batches).  209 sequential field products per digest instead of 365:
-// a lone wave finishes in ~0.10 ms instead of 0.165.  Exchange: the five S-box outputs of a full round travel by
-// ds_bpermute_b32 (the LDS crossbar, no LDS memory: 45 per round, issued back to back), the one element a partial
-// round swaps inside a lane pair by DPP quad_perm [1,0,3,2] on v_mov_b32 (VALU, no wait).  `lanes` >= 8 n: as in
-// k_merkle4_pad, group g hashes node g mod n so that a large tree's narrow levels keep every SIMD busy. ----
-struct WaveComm {
+// ---- the low-latency digest: ONE node per group of 8 (or 4) lanes (coop29.hpp) — for launches that cannot fill the
+// chip anyway (a tree's levels of <= 16,384 nodes, small batches).  209 (233) sequential field products per digest instead
+// of 365: a lone wave finishes in 0.12 ms instead of 0.17.  Exchange, 8 lanes: the five S-box outputs of a full round
+// travel by ds_bpermute_b32 (the LDS crossbar, no LDS memory: 45 per round, issued back to back, one wait); 4 lanes: by
+// DPP quad_perm broadcast on v_mov_b32 (VALU, no wait).  The one element a partial round swaps inside a lane pair:
+// DPP quad_perm [1,0,3,2].  `lanes` >= LANES * n: as in k_merkle4_pad, group g hashes node g mod n so that a large
+// tree's narrow levels keep every SIMD busy. ----
+struct WaveComm8 {
     int j;      // my index within the group
     int base4;  // ds_bpermute byte address of my group's lane 0 (within the wave)
     __device__ __forceinline__ int lane() const { return j; }
-    __device__ __forceinline__ E29 get(const E29& v, int src) const {
+    template <int M>
+    __device__ __forceinline__ E29 get(const E29& v) const {
         E29 r;
-        const int addr = base4 + 4 * src;
+        const int addr = base4 + 4 * M;
 #pragma unroll
         for (int k = 0; k < NL; ++k) r.d[k] = __builtin_amdgcn_ds_bpermute(addr, v.d[k]);
         return r;
@@ -152,25 +154,54 @@ struct WaveComm {
         return r;
     }
 };
+struct WaveComm4 {  // a group = a quad
+    int j;
+    __device__ __forceinline__ int lane() const { return j; }
+    template <int M>
+    __device__ __forceinline__ E29 get(const E29& v) const {
+        E29 r;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) r.d[k] = __builtin_amdgcn_mov_dpp(v.d[k], M * 0x55 /* quad_perm [M,M,M,M] */, 0xf, 0xf, true);
+        return r;
+    }
+    __device__ __forceinline__ E29 swap1(const E29& v) const {
+        E29 r;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) r.d[k] = __builtin_amdgcn_mov_dpp(v.d[k], 0xB1, 0xf, 0xf, true);
+        return r;
+    }
+};
+__device__ __forceinline__ E29 load_child_or_zero(const Scalar32* __restrict__ children, size_t n_children, size_t idx,
+                                                  unsigned arity, int k /* child number, < 0: none */) {
+    const size_t c = idx * arity + (size_t)(k > 0 ? k : 0);
+    const bool present = k >= 0 && (unsigned)k < arity && c < n_children;
+    return present ? load_scalar(children + c) : e29_zero();
+}
+template <int LANES>
 __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __restrict__ tab, TagArg tag,
                                                              const Scalar32* __restrict__ children,
                                                              size_t n_children, Scalar32* __restrict__ out,
                                                              size_t n, unsigned arity, size_t lanes) {
     const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (lane >= lanes) return;  // (lanes is a multiple of 8: whole groups only)
-    const size_t idx = (lane / COOP_LANES) % n;
-    const int j = (int)(threadIdx.x & (COOP_LANES - 1));
-    const int el = j < WIDTH ? j : WIDTH - 1;  // the state element this lane brings: 0 = tag, 1..4 = children
+    const size_t idx = (lane / LANES) % n;
+    const int j = (int)(threadIdx.x & (LANES - 1));
+    const int el = LANES == 8 ? (j < WIDTH ? j : WIDTH - 1) : j;  // the state element this lane brings: 0 = tag, 1..4 = children
     E29 mine = from_mont4(tag.w);
     {
-        const size_t c = idx * arity + (size_t)(el > 0 ? el - 1 : 0);
-        const bool present = el > 0 && (unsigned)(el - 1) < arity && c < n_children;
-        const E29 child = present ? load_scalar(children + c) : e29_zero();
+        const E29 child = load_child_or_zero(children, n_children, idx, arity, el - 1);
 #pragma unroll
         for (int k = 0; k < NL; ++k) mine.d[k] = el > 0 ? child.d[k] : mine.d[k];
     }
-    WaveComm cm{j, (int)(((threadIdx.x & 63u) & ~(unsigned)(COOP_LANES - 1)) * 4u)};
-    const E29 r = merkle4_digest_coop(mine, tab, cm);
+    E29 r;
+    if (LANES == 8) {
+        WaveComm8 cm{j, (int)(((threadIdx.x & 63u) & ~7u) * 4u)};
+        r = merkle4_digest_coop<8>(mine, mine, tab, cm);
+    } else {
+        const E29 last = load_child_or_zero(children, n_children, idx, arity, 3);  // element 4 travels on every lane
+        WaveComm4 cm{j};
+        r = merkle4_digest_coop<4>(mine, last, tab, cm);
+    }
     if (j == 0) store_scalar(out + idx, r);
 }
 
@@ -379,16 +410,22 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
                           void* out, size_t n, hipStream_t st, unsigned arity, size_t pad_lanes) {
     if (n == 0) return hipSuccess;
-    // launches of at most one wave per SIMD with 8 lanes per node: the cooperative low-latency build
+    // launches of at most one wave per SIMD with 8 (4) lanes per node: the cooperative low-latency builds
+    // (P252_COOP_MAX_NODES: largest launch that may use them, default 16384; 0 = never)
     static const size_t coop_max = [] {
         const char* e = std::getenv("P252_COOP_MAX_NODES");
-        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)8192;
+        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)16384;
     }();
-    if (n <= coop_max) {
-        const size_t want = n * COOP_LANES;
+    if (n <= coop_max && n * 4 <= (size_t)65536) {
+        const bool eight = n * 8 <= (size_t)65536;
+        const size_t want = n * (eight ? 8 : 4);
         const size_t lanes = want < pad_lanes ? pad_lanes : want;
-        hipLaunchKernelGGL(k_merkle4_coop, dim3(grid_for(lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
-                           static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, lanes);
+        if (eight)
+            hipLaunchKernelGGL(k_merkle4_coop<8>, dim3(grid_for(lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, lanes);
+        else
+            hipLaunchKernelGGL(k_merkle4_coop<4>, dim3(grid_for(lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, lanes);
         return hipGetLastError();
     }
     if (n < pad_lanes) {
@@ -396,8 +433,16 @@ hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* chi
                            static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, pad_lanes);
         return hipGetLastError();
     }
-    // <= one wave per SIMD on the whole chip (256 CUs x 4 SIMDs x 64 lanes): the latency build
-    if (n <= (size_t)65536)
+    // <= one wave per SIMD on the whole chip (256 CUs x 4 SIMDs x 64 lanes): the latency build (169 VGPRs: two waves per
+    // SIMD).  It also takes launches of two and of FOUR waves per SIMD: at three resident waves a fourth runs alone
+    // afterwards at a lone wave's latency (3 + 1), two and two do not (2^18 digests: see profiles/r02_ab_coop.txt).
+    // (P252_LAT_WAVES: bit w set = launches of w waves per SIMD use it; default 0x16 = {1, 2, 4})
+    static const unsigned lat_mask = [] {
+        const char* e = std::getenv("P252_LAT_WAVES");
+        return e ? (unsigned)std::strtoul(e, nullptr, 0) : 0x16u;
+    }();
+    const size_t waves_per_simd = (n + 65535) / 65536;
+    if (waves_per_simd < 32 && ((lat_mask >> waves_per_simd) & 1u))
         hipLaunchKernelGGL(k_merkle4_lat, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                            static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity);
     else

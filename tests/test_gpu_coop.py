@@ -1,6 +1,7 @@
-"""The low-latency digest kernel (k_merkle4_coop: one node per group of eight lanes, coop29.hpp) — what every launch of
-at most 8,192 Merkle digests runs — against the oracle: batch sizes around a group / a wave / a block / the switch to
-the one-lane kernels, ragged children, arity 2, saturated limbs, and byte equality with the one-lane kernels."""
+"""The low-latency digest kernels (k_merkle4_coop<8> / <4>: one node per group of eight / four lanes, coop29.hpp) — what
+every launch of at most 8,192 / 16,384 Merkle digests runs — against the oracle: batch sizes around a group / a wave /
+a block / the switches between the kernels, ragged children, arity 2, saturated limbs, and byte equality with the
+one-lane kernels."""
 import os
 import subprocess
 import sys
@@ -12,7 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 31, 32, 33, 255, 256, 257, 8191, 8192, 8193])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 31, 32, 33, 255, 256, 257, 8191, 8192, 8193, 12345, 16383, 16384, 16385])
 def test_digest_batches_around_the_group_and_switch_sizes(gpu_ctx, oracle_mod, n):
     tag = oracle_mod.tag(0, [4], 1)
     x = oracle_mod.fill_random(50 + n, 4 * n).reshape(n, 4, 4)
@@ -21,12 +22,13 @@ def test_digest_batches_around_the_group_and_switch_sizes(gpu_ctx, oracle_mod, n
     assert np.array_equal(gpu_ctx.hash_batch(tag2, x[:, :2], 2, 1), oracle_mod.hash_batch(tag2, np.ascontiguousarray(x[:, :2]), 2, 1))
 
 
-def test_saturated_limbs_and_edge_values(gpu_ctx, oracle_mod):
+@pytest.mark.parametrize("n_items", [600, 9000])  # the 8-lane and the 4-lane kernel
+def test_saturated_limbs_and_edge_values(gpu_ctx, oracle_mod, n_items):
     P = oracle_mod.P
     pats = [(1 << 256) - 1, (1 << 255) + 12345, P, P + 1, 2 * P - 1, int("55" * 32, 16), int("aa" * 32, 16), 0, 1, P - 1,
             sum(((1 << 29) - 1) << (29 * i) for i in range(8)) | (((1 << 24) - 1) << 232), (1 << 256) - (1 << 200)]
     rng = np.random.default_rng(3)
-    pick = rng.integers(0, len(pats), size=(600, 4))
+    pick = rng.integers(0, len(pats), size=(n_items, 4))
     raw = np.array([[oracle_mod.int_to_limbs(pats[k]) for k in row] for row in pick], dtype=np.uint64)
     red = np.array([[oracle_mod.int_to_limbs(pats[k] % P) for k in row] for row in pick], dtype=np.uint64)
     for tag in (oracle_mod.tag(0, [4], 1), np.array(oracle_mod.int_to_limbs((1 << 256) - 5), dtype=np.uint64)):
@@ -35,7 +37,7 @@ def test_saturated_limbs_and_edge_values(gpu_ctx, oracle_mod):
         assert np.array_equal(got, oracle_mod.hash_batch(tag_red, red, 4, 1))
 
 
-@pytest.mark.parametrize("n_leaves", [6, 13, 4 ** 6, 4 ** 6 + 1, 3 * 4 ** 6 + 5, 4 ** 7 + 3])
+@pytest.mark.parametrize("n_leaves", [6, 13, 4 ** 6, 4 ** 6 + 1, 3 * 4 ** 6 + 5, 4 ** 7 + 3, 4 ** 8, 50001])
 def test_trees_whose_levels_run_on_the_cooperative_kernel(gpu_ctx, oracle_mod, n_leaves):
     tag = oracle_mod.tag(0, [4], 1)
     lv = oracle_mod.fill_random(n_leaves, n_leaves)
@@ -45,14 +47,14 @@ def test_trees_whose_levels_run_on_the_cooperative_kernel(gpu_ctx, oracle_mod, n
 
 
 def test_same_bytes_as_the_one_lane_kernels():
-    """P252_COOP_MAX_NODES=0 (read once per process, hence the subprocesses) sends every launch to k_merkle4_lat:
+    """P252_COOP_MAX_NODES=0 (read once per process, hence the subprocesses) sends every launch to the one-lane kernels:
     digests and tree levels must be the same bytes either way"""
     code = r'''
 import hashlib, numpy as np, oracle, poseidon252_amd as P
 ctx = P.Context(0)
 tag = P.merkle4_tag()
 h = hashlib.sha256()
-for n in (1, 9, 300, 8192):
+for n in (1, 9, 300, 8192, 12000):
     x = oracle.fill_random(70 + n, 4 * n).reshape(n, 4, 4)
     h.update(ctx.hash_batch(tag, x, 4, 1).tobytes())
 root, levels = P.merkle4_tree(oracle.fill_random(9, 70001), tag=tag, ctx=ctx, want_levels=True)
@@ -60,7 +62,7 @@ h.update(root.tobytes()); h.update(levels.tobytes())
 print("DIGEST", h.hexdigest())
 '''
     outs = []
-    for coop in ("8192", "0"):
+    for coop in ("16384", "0"):
         env = dict(os.environ, P252_COOP_MAX_NODES=coop)
         r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(HERE), env=env, capture_output=True, timeout=600)
         assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()

@@ -4,6 +4,7 @@ import ctypes
 import random
 
 import numpy as np
+import pytest
 
 import pymodel
 
@@ -255,10 +256,11 @@ def test_digest_path_with_hoisted_tag_sbox(oracle_mod, hosttest_lib):
     assert np.array_equal(a, b)
 
 
-def test_cooperative_digest_eight_lanes(oracle_mod, hosttest_lib):
-    """coop29.hpp — one digest computed by a group of eight lanes (the low-latency kernel k_merkle4_coop), with the lanes
-    played by eight host threads and the cross-lane exchange by a barrier: all eight lanes return the oracle's digest for
-    random, edge and non-canonical children and tags, and the reductions stay inside the same column / digit bounds."""
+@pytest.mark.parametrize("lanes", [8, 4])
+def test_cooperative_digest_lane_groups(oracle_mod, hosttest_lib, lanes):
+    """coop29.hpp — one digest computed by a group of eight (or four) lanes (the low-latency kernels k_merkle4_coop<8|4>),
+    with the lanes played by host threads and the cross-lane exchange by a barrier: every lane returns the oracle's digest
+    for random, edge and non-canonical children and tags, and the reductions stay inside the same column / digit bounds."""
     import math
     for f in (hosttest_lib.ht_bounds_max_col, hosttest_lib.ht_bounds_max_top, hosttest_lib.ht_bounds_max_top1):
         f.restype = ctypes.c_double
@@ -271,7 +273,7 @@ def test_cooperative_digest_eight_lanes(oracle_mod, hosttest_lib):
     for tag in (oracle_mod.tag(0, [4], 1), np.zeros(4, dtype=np.uint64), oracle_mod.fill_random(6, 1)[0]):
         tag = np.ascontiguousarray(tag, dtype=np.uint64)
         out = np.empty((n, 4), dtype=np.uint64)
-        hosttest_lib.ht_merkle4_digest_coop(p(tag), p(x), p(out), n)
+        assert hosttest_lib.ht_merkle4_digest_coop(p(tag), p(x), p(out), n, lanes) == 0
         assert np.array_equal(out, oracle_mod.hash_batch(tag, x, 4, 1).reshape(n, 4))
     # saturated 256-bit patterns (not residues below p): the same class as their reduction, on every lane
     pats = [(1 << 256) - 1, (1 << 255) + 12345, P, 2 * P - 1, int("aa" * 32, 16), (1 << 256) - (1 << 200)]
@@ -279,11 +281,11 @@ def test_cooperative_digest_eight_lanes(oracle_mod, hosttest_lib):
     red = np.array([[oracle_mod.int_to_limbs(pats[(i + k) % len(pats)] % P) for k in range(4)] for i in range(12)], dtype=np.uint64)
     tag = np.ascontiguousarray(oracle_mod.tag(0, [4], 1), dtype=np.uint64)
     a, b = np.empty((12, 4), dtype=np.uint64), np.empty((12, 4), dtype=np.uint64)
-    hosttest_lib.ht_merkle4_digest_coop(p(tag), p(raw), p(a), 12)
-    hosttest_lib.ht_merkle4_digest_coop(p(tag), p(red), p(b), 12)
+    hosttest_lib.ht_merkle4_digest_coop(p(tag), p(raw), p(a), 12, lanes)
+    hosttest_lib.ht_merkle4_digest_coop(p(tag), p(red), p(b), 12, lanes)
     assert np.array_equal(a, b) and np.array_equal(b, oracle_mod.hash_batch(tag, red, 4, 1).reshape(12, 4))
     col, top = hosttest_lib.ht_bounds_max_col(), hosttest_lib.ht_bounds_max_top()
     if col >= 0:
         assert 2 ** 58 < col < 2 ** 62.6, math.log2(col)
         assert top < 2 ** 27, math.log2(top)
-        print("cooperative schedule: max |column| 2^%.2f, max |top digit| 2^%.2f" % (math.log2(col), math.log2(top)))
+        print("cooperative schedule, %d lanes: max |column| 2^%.2f, max |top digit| 2^%.2f" % (lanes, math.log2(col), math.log2(top)))

@@ -15,7 +15,7 @@ def test_committed_isa_counts_match_the_sources():
     path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_counts.json")))[-1]
     committed = json.load(open(path))
     text = open(ic.compile_asm()).read()
-    for kernel in ("k_merkle4", "k_permute"):
+    for kernel in ("k_merkle4", "k_permute", "k_merkle4_coop<8>", "k_merkle4_coop<4>"):
         now = ic.count_kernel(text, kernel)
         for key in ("valu_total", "v_mad_i64_i32", "valu_4cycle_class", "valu_2cycle_class", "valu_issue_cycles"):
             assert now[key] == committed[kernel][key], (kernel, key, now[key], committed[kernel][key])
@@ -23,6 +23,14 @@ def test_committed_isa_counts_match_the_sources():
     # one v_mad_i64_i32 per digit product: 100 S-boxes minus the hoisted one, 60 G-products, ...
     assert 60_000 < m4["v_mad_i64_i32"] < 64_000 and m4["v_mad_i64_i32"] < pm["v_mad_i64_i32"]
     assert m4["valu_total"] < 81_000  # round 1: 84,606
+    # the cooperative digest (eight lanes per node): about two thirds of the one-lane instruction stream per lane
+    co, c4 = committed["k_merkle4_coop<8>"], committed["k_merkle4_coop<4>"]
+    assert co["valu_total"] < 0.67 * m4["valu_total"] and co["v_mad_i64_i32"] < 0.65 * m4["v_mad_i64_i32"]
+    assert co["valu_total"] < c4["valu_total"] < 0.75 * m4["valu_total"]
+    # 45 ds_bpermute per full round (8 lanes) / 36 DPP broadcasts (4 lanes), 9 DPP moves per partial round
+    assert co["lds"] == 8 * 45 and co["by_mnemonic"]["v_mov_b32_dpp"] == 60 * 9
+    assert c4["lds"] == 0 and c4["by_mnemonic"]["v_mov_b32_dpp"] == 60 * 9 + 8 * 36
+    assert m4["lds"] == 0
     # nothing but multiply-adds, the carry chains' shift / add / mask and the steps' xor in any quantity
     top = list(m4["by_mnemonic"].items())[:6]
     assert top[0][0] == "v_mad_i64_i32" and {k for k, _ in top[1:]} <= {"v_and_b32_e32", "v_lshl_add_u64", "v_xor_b32_e32", "v_ashrrev_i64",

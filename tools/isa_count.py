@@ -49,11 +49,14 @@ def kernel_body(asm_text, name):
     """lines of the function whose mangled name contains `name` (label .. s_endpgm)"""
     lines = asm_text.splitlines()
     start = None
+    t = re.fullmatch(r"(\w+)<(\d+)>", name)  # a template instance: k_merkle4_coop<8> -> ...k_merkle4_coopILi8EE...
+    pat = r"\d+%sILi%sEE" % (t.group(1), t.group(2)) if t else r"\d+%s[EI]" % re.escape(name)
+    name = t.group(1) if t else name
     for i, l in enumerate(lines):
         m = re.match(r"^(_Z\w+):", l)
         if m and name in m.group(1):
             # exact kernel: "9k_merkle4E" must not match "14k_merkle4_pathE"
-            if re.search(r"\d+%s[EI]" % re.escape(name), m.group(1)):
+            if re.search(pat, m.group(1)):
                 start = i
                 break
     if start is None:
@@ -336,6 +339,7 @@ def summarise(counts):
         "salu": sum(v for k, v in counts.items() if k.startswith("s_") and not k.startswith(("s_load", "s_waitcnt", "s_nop", "s_endpgm"))),
         "smem": sum(v for k, v in counts.items() if k.startswith("s_load")),
         "vmem": sum(v for k, v in counts.items() if k.startswith(("global_", "buffer_", "flat_", "scratch_"))),
+        "lds": sum(v for k, v in counts.items() if k.startswith("ds_")),  # (ds_bpermute_b32: the cooperative kernel's cross-lane moves)
         "by_mnemonic": dict(sorted(valu.items(), key=lambda kv: -kv[1])),
     }
 
@@ -348,13 +352,13 @@ def count_kernel(asm_text, kernel, args=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--asm", help="assembly file (default: compile kernels.hip now)")
-    ap.add_argument("--kernel", action="append", help="kernel name (default: k_merkle4 and k_permute)")
+    ap.add_argument("--kernel", action="append", help="kernel name (default: k_merkle4, k_permute, k_merkle4_coop<8> and k_merkle4_coop<4>)")
     ap.add_argument("--out")
     a = ap.parse_args()
     path = a.asm or compile_asm()
     text = open(path).read()
     res = {}
-    for k in a.kernel or ["k_merkle4", "k_permute"]:
+    for k in a.kernel or ["k_merkle4", "k_permute", "k_merkle4_coop<8>", "k_merkle4_coop<4>"]:
         res[k] = count_kernel(text, k)
     res["_note"] = ("instructions issued by ONE wave for one pass of the kernel (per lane: one Merkle4 digest / one permutation), from the "
                     "ISA of kernels.hip at this commit: scalar control flow interpreted, vector instructions counted (tools/isa_count.py)")
