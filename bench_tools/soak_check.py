@@ -27,3 +27,14 @@ while time.time() - t0 < 40:
     assert np.array_equal(ctx.hash_batch(tag, msg, in_len, out_len), oracle.hash_batch(tag, msg, in_len, out_len, threads=8)), (in_len, out_len, n)
     checked += n
 print("%d random-shape sponge messages bit-exact" % checked)
+# Merkle digests through the cooperative kernels (<= 8,192 nodes: 8 lanes per node; <= 16,384: 4 lanes) and across the
+# switches to the one-lane kernels
+checked = 0
+t0 = time.time()
+mtag = oracle.tag(0, [4], 1)
+while time.time() - t0 < 25:
+    n = int(rng.choice([int(rng.integers(1, 600)), int(rng.integers(600, 8193)), int(rng.integers(8193, 16385)), int(rng.integers(16385, 70000))]))
+    x = oracle.fill_random(int(rng.integers(1, 1 << 30)), 4 * n).reshape(n, 4, 4)
+    assert np.array_equal(ctx.hash_batch(mtag, x, 4, 1), oracle.hash_batch(mtag, x, 4, 1, threads=8)), n
+    checked += n
+print("%d Merkle4 digests in batches of 1 .. 70,000 bit-exact" % checked)

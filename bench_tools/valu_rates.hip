@@ -51,7 +51,7 @@ constexpr int REP = 4;  // asm block repeated REP times per loop iteration; each
         if (s == 12345u) sink[threadIdx.x] = s;                                             \
     }
 // 64-bit chains (VGPR pairs): %0..%7 chains, %8 = b, %9 = c (32-bit vgprs), %10 = sarg, %11 = 64-bit vgpr pair
-#define DEFINE_KERNEL64(NAME, ASM8, CLOB)                                                   \
+#define DEFINE_KERNEL64(NAME, ASM8, ...)                                                  \
     __global__ void __launch_bounds__(256) k_##NAME(unsigned* sink, unsigned sarg, int niter) { \
         unsigned long long a0 = (threadIdx.x * 2654435761u + 7u) * 0x9e3779b97f4a7c15ull, a1 = a0 * 3, a2 = a0 * 5, \
                            a3 = a0 * 7, a4 = a0 * 9, a5 = a0 * 11, a6 = a0 * 13, a7 = a0 * 15; \
@@ -62,7 +62,7 @@ constexpr int REP = 4;  // asm block repeated REP times per loop iteration; each
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), \
                                 "+v"(a6), "+v"(a7)                                          \
                               : "v"(b), "v"(c), "s"(sarg), "v"(b64)                         \
-                              : CLOB);)                                                     \
+                              : __VA_ARGS__);)                                                     \
         }                                                                                   \
         unsigned long long s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                       \
         if (s == 12345ull) sink[threadIdx.x] = (unsigned)s;                                 \
@@ -144,6 +144,32 @@ DEFINE_KERNEL64(mix_step_wide,
                 "v_mad_i64_i32 %4, vcc, %8, %10, %4\nv_mad_i64_i32 %5, vcc, %8, %10, %5\nv_mad_i64_i32 %6, vcc, %8, %10, %6\nv_mad_i64_i32 %7, vcc, %8, %10, %7\n"
                 "v_mad_i64_i32 %0, vcc, %9, %10, %0\n", "vcc")
 
+// Does the carry-out register matter?  v_mad_i64_i32 / v_add_co_u32 (VOP3b) write an SGPR pair; every stream above names
+// vcc.  Same streams with the carry-outs rotating over 8 / 2 different SGPR pairs (--sdst).
+#define MAD_SD(A, SD) "v_mad_i64_i32 " A ", " SD ", %8, %10, " A "\n"
+DEFINE_KERNEL64(mad_sdst_rot8,
+                MAD_SD("%0", "s[36:37]") MAD_SD("%1", "s[38:39]") MAD_SD("%2", "s[40:41]") MAD_SD("%3", "s[42:43]")
+                MAD_SD("%4", "s[44:45]") MAD_SD("%5", "s[46:47]") MAD_SD("%6", "s[48:49]") MAD_SD("%7", "s[50:51]"),
+                "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51")
+DEFINE_KERNEL64(mad_sdst_rot2,
+                MAD_SD("%0", "s[36:37]") MAD_SD("%1", "s[38:39]") MAD_SD("%2", "s[36:37]") MAD_SD("%3", "s[38:39]")
+                MAD_SD("%4", "s[36:37]") MAD_SD("%5", "s[38:39]") MAD_SD("%6", "s[36:37]") MAD_SD("%7", "s[38:39]"),
+                "s36", "s37", "s38", "s39")
+DEFINE_KERNEL64(mad_sdst_one,
+                MAD_SD("%0", "s[36:37]") MAD_SD("%1", "s[36:37]") MAD_SD("%2", "s[36:37]") MAD_SD("%3", "s[36:37]")
+                MAD_SD("%4", "s[36:37]") MAD_SD("%5", "s[36:37]") MAD_SD("%6", "s[36:37]") MAD_SD("%7", "s[36:37]"),
+                "s36", "s37")
+DEFINE_KERNEL64(mix_step_wide_rot,
+                "v_xor_b32 %8, 0x80000000, %8\n"
+                MAD_SD("%0", "s[36:37]") MAD_SD("%1", "s[38:39]") MAD_SD("%2", "s[40:41]") MAD_SD("%3", "s[42:43]")
+                MAD_SD("%4", "s[44:45]") MAD_SD("%5", "s[46:47]") MAD_SD("%6", "s[48:49]") MAD_SD("%7", "s[50:51]")
+                "v_mad_i64_i32 %0, s[52:53], %9, %10, %0\n",
+                "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53")
+// interleaved with 2-cycle work: does a plain op between two multiply-adds hide the carry-out's extra cycle?
+DEFINE_KERNEL64(mad_and_interleaved,
+                "v_mad_i64_i32 %0, vcc, %8, %10, %0\nv_and_b32 %9, %9, %8\nv_mad_i64_i32 %1, vcc, %8, %10, %1\nv_and_b32 %9, %9, %8\n"
+                "v_mad_i64_i32 %2, vcc, %8, %10, %2\nv_and_b32 %9, %9, %8\nv_mad_i64_i32 %3, vcc, %8, %10, %3\nv_and_b32 %9, %9, %8\n", "vcc")
+
 // one dependent chain per wave: what a lone wave pays per instruction (the tree's narrow levels, small batches)
 #define DEFINE_LAT(NAME, TYPE, ASM1, CLOB)                                                  \
     __global__ void __launch_bounds__(256) k_lat_##NAME(unsigned* sink, unsigned sarg, int niter) { \
@@ -167,9 +193,10 @@ struct Entry {
 };
 
 int main(int argc, char** argv) {
-    bool with_latency = false, clock_mode = false;
+    bool with_latency = false, clock_mode = false, sdst_mode = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--latency")) with_latency = true;
+        if (!strcmp(argv[i], "--sdst")) sdst_mode = true;    // only the carry-out-register experiment
         if (!strcmp(argv[i], "--clock")) clock_mode = true;  // short run for `rocprofv3 --pmc GRBM_GUI_ACTIVE`: few, long launches
     }
     hipDeviceProp_t prop;
@@ -196,6 +223,16 @@ int main(int argc, char** argv) {
         {"mix: tight step (and+8mad+ashr64+add64)", k_mix_step_tight, 11, false},
         {"mix: wide step (xor+9mad)", k_mix_step_wide, 10, false},
     };
+    if (sdst_mode) {
+        tests = {{"v_mad_i64_i32 sdst = vcc", k_mad_i64_i32_s, 8, false},
+                 {"v_mad_i64_i32 sdst = one SGPR pair", k_mad_sdst_one, 8, false},
+                 {"v_mad_i64_i32 sdst rotating over 2 pairs", k_mad_sdst_rot2, 8, false},
+                 {"v_mad_i64_i32 sdst rotating over 8 pairs", k_mad_sdst_rot8, 8, false},
+                 {"mix: wide step (xor+9mad), sdst = vcc", k_mix_step_wide, 10, false},
+                 {"mix: wide step (xor+9mad), sdst rotating", k_mix_step_wide_rot, 10, false},
+                 {"mix: mad / v_and alternating (8 per block)", k_mad_and_interleaved, 8, false},
+                 {"v_lshl_add_u64", k_lshl_add_u64, 8, false}};
+    }
     if (with_latency) {
         tests.push_back({"lone wave, 1 chain: v_mad_i64_i32", k_lat_mad_i64_i32, 8, true});
         tests.push_back({"lone wave, 1 chain: v_and_b32", k_lat_and_b32, 8, true});
@@ -235,7 +272,7 @@ int main(int argc, char** argv) {
     const double nominal_simd_cycles = 1024.0 * 2.4e9;
     printf("%-44s %6s %14s %16s %18s\n", "instruction", "w/SIMD", "Gwave-inst/s", "inst/SIMD-cycle", "cycles/inst/SIMD");
     for (auto& t : tests) {
-        const bool is_mad = strstr(t.name, "v_mad_i64_i32 (sgpr)") || strstr(t.name, "mix:");
+        const bool is_mad = sdst_mode || strstr(t.name, "v_mad_i64_i32 (sgpr)") || strstr(t.name, "mix:");
         for (int k : {1, 2, 3, 4, 6, 8}) {
             if (t.latency && k != 1) continue;
             if (!is_mad && (k == 3 || k == 6 || k == 8)) continue;  // the occupancy sweep only where it matters
