@@ -84,46 +84,59 @@ P252_HD E29 coop_int_row(const E29 xs[WIDTH], const int32_t hn[WIDTH], const int
     return row_redc1(t);
 }
 
-// The digest of one node.  LANES = 8: lane i (< 5) passes state element i (the tag, then the four children; lanes 5..7
-// anything) and `element4` is ignored.  LANES = 4: lane i passes element i and every lane passes element 4 as well.
-// Every lane returns perm(state)[1] at the reference's Montgomery scale (lazy; to_mont4 canonicalises).
+// What a lane keeps for the whole kernel: its place in the group and its rows of the small constant tables.  Per-lane
+// table rows are vector loads (~1 us of latency) with nothing to overlap them at their point of use, which is where the
+// optimiser sinks them; so they are fetched ahead: hn / c0 once per kernel, the kappa of round f + 1 while round f runs
+// (round 7 fetches round 0's for the next permutation of the same kernel; round 4's is fetched ahead of the exit row),
+// the exit row ahead of the entry rows — each pinned (pin_loaded) where it must have been issued.
+template <int LANES>
+struct CoopLane {
+    static constexpr int OWN = LANES == 8 ? WIDTH : 4;  // state elements that live on a lane of their own
+    int lane, row;        // row = my state element = my row of the linear layers (lanes >= OWN shadow the last one)
+    bool odd;
+    int32_t hn[WIDTH];    // my row of the integer MDS matrix (Hankel: h[row + m])
+    int32_t c0[NL];       // first round constant of my element
+    int32_t kap[NL];      // kappa of the NEXT full round to run, my row (round 0's between permutations)
+};
+template <class TP>
+P252_HD void coop_load_kappa(int32_t kap[NL], TP tab, int f, int row) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) kap[k] = lane_const(tab, Tab29Layout::AI_KAPPA + (f * WIDTH + row) * NL + k);
+}
 template <int LANES, class Comm, class TP>
-P252_HD E29 merkle4_digest_coop(const E29& element, const E29& element4, TP tab, Comm& cm) {
+P252_HD CoopLane<LANES> coop_lane(TP tab, Comm& cm) {
+    typedef Tab29Layout Lay;
+    CoopLane<LANES> L;
+    L.lane = cm.lane();
+    L.row = L.lane < CoopLane<LANES>::OWN ? L.lane : CoopLane<LANES>::OWN - 1;
+    L.odd = (L.lane & 1) != 0;
+#pragma unroll
+    for (int m = 0; m < WIDTH; ++m) L.hn[m] = lane_const(tab, Lay::INT_N + L.row + m);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) L.c0[k] = lane_const(tab, Lay::C_FIRST + L.row * NL + k);
+    coop_load_kappa(L.kap, tab, 0, L.row);
+    return L;
+}
+
+// One permutation on a group.  In: s = my state element (lane i < OWN: element i; LANES = 8: lanes 5..7 anything),
+// s4 = element 4 on every lane (LANES = 4 only).  Out: s = my element of the permuted state (lane i < OWN), s4 = element 4
+// (LANES = 4), at the reference's Montgomery scale (lazy; to_mont4 canonicalises).  ROW4 = false (a digest: only element
+// 1 is squeezed) skips the last layer's row 4 and its scaling on the 4-lane groups.
+template <int LANES, bool ROW4 = true, class Comm, class TP>
+P252_HD void hades_permute_coop(E29& s, E29& s4, TP tab, Comm& cm, CoopLane<LANES>& L) {
     static_assert(LANES == 8 || LANES == 4, "group sizes: 8 (five S-boxes side by side) or 4 (element 4 on every lane)");
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
-    constexpr int OWN = LANES == 8 ? WIDTH : 4;  // state elements that live on a lane of their own
     const RK K = make_rk();
-    const int lane = cm.lane();
-    const int row = lane < OWN ? lane : OWN - 1;  // my state element / my row of the linear layers
-    const bool odd = (lane & 1) != 0;
-    int32_t hn[WIDTH];
-#pragma unroll
-    for (int m = 0; m < WIDTH; ++m) hn[m] = tab[Lay::INT_N + row + m];
-    E29 s = element, s4 = element4;
-    {
-        int32_t c0[NL];
-#pragma unroll
-        for (int k = 0; k < NL; ++k) c0[k] = tab[Lay::C_FIRST + row * NL + k];
-        add_c(s, c0);
-        if (LANES == 4) add_c(s4, tab + Lay::C_FIRST + 4 * NL);
-    }
-    // Per-lane constants (my row's kappa, my exit row) are vector loads with ~1 us of latency and nothing to overlap it
-    // at their point of use, which is where the optimiser sinks them.  They are fetched one step ahead instead: round
-    // f + 1's kappa as a loop-carried value while round f runs, the exit row before the entry rows, pinned (pin_loaded)
-    // ahead of the 60 partial rounds.
-    int32_t kap[NL];
-#pragma unroll
-    for (int k = 0; k < NL; ++k) kap[k] = lane_const(tab, Lay::AI_KAPPA + row * NL + k);
+    add_c(s, L.c0);
+    if (LANES == 4) add_c(s4, tab + Lay::C_FIRST + 4 * NL);
     E29 xs[WIDTH];
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
 #pragma unroll 1
         for (int f = half * RF; f < (half + 1) * RF; ++f) {
             int32_t kap_next[NL];
-            const int fn = f + 1 < 2 * RF ? f + 1 : f;
-#pragma unroll
-            for (int k = 0; k < NL; ++k) kap_next[k] = lane_const(tab, Lay::AI_KAPPA + (fn * WIDTH + row) * NL + k);
+            if (f != RF - 1) coop_load_kappa(kap_next, tab, (f + 1) % (2 * RF), L.row);  // (round 3 has no row: the entry)
             const E29 x = sbox_w(s, K);
             xs[0] = cm.template get<0>(x);
             xs[1] = cm.template get<1>(x);
@@ -133,16 +146,17 @@ P252_HD E29 merkle4_digest_coop(const E29& element, const E29& element4, TP tab,
                 xs[4] = cm.template get<4>(x);
             else
                 xs[4] = sbox_w(s4, K);
-            if (f != RF - 1 && f != 2 * RF - 1) {
-                s = coop_int_row(xs, hn, kap);
-                if (LANES == 4) s4 = int_row(xs, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + (f * WIDTH + 4) * NL);
-            }
+            if (f != RF - 1) {
+                s = coop_int_row(xs, L.hn, L.kap);
+                if (LANES == 4 && (ROW4 || f != 2 * RF - 1))
+                    s4 = int_row(xs, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + (f * WIDTH + 4) * NL);
 #pragma unroll
-            for (int k = 0; k < NL; ++k) kap[k] = kap_next[k];
+                for (int k = 0; k < NL; ++k) L.kap[k] = kap_next[k];
+            }
         }
         if (half == 0) {
             // my exit row's constants (hidden by the entry and the 60 rounds below)
-            const int er = lane < 4 ? lane : 3;
+            const int er = L.lane < 4 ? L.lane : 3;
             int32_t exn[2 * NL], exfix[NL], exadd[NL];
 #pragma unroll
             for (int k = 0; k < 2 * NL; ++k) exn[k] = lane_const(tab, Lay::AI_EX_N + er * 2 * NL + k);
@@ -163,23 +177,24 @@ P252_HD E29 merkle4_digest_coop(const E29& element, const E29& element4, TP tab,
 #pragma unroll 1
             for (int it = 0; it < PARTIAL_ROUNDS / HIST; ++it) {
                 const TP kg = tab + Lay::AI_KG + it * HIST * 2 * NL;
-                coop_ai_round<1>(Us, Ws, tab + Lay::AI_AB, kg, odd, K, cm);
-                coop_ai_round<2>(Us, Ws, tab + Lay::AI_AB, kg + 2 * NL, odd, K, cm);
-                coop_ai_round<3>(Us, Ws, tab + Lay::AI_AB, kg + 4 * NL, odd, K, cm);
-                coop_ai_round<4>(Us, Ws, tab + Lay::AI_AB, kg + 6 * NL, odd, K, cm);
-                coop_ai_round<0>(Us, Ws, tab + Lay::AI_AB, kg + 8 * NL, odd, K, cm);
+                coop_ai_round<1>(Us, Ws, tab + Lay::AI_AB, kg, L.odd, K, cm);
+                coop_ai_round<2>(Us, Ws, tab + Lay::AI_AB, kg + 2 * NL, L.odd, K, cm);
+                coop_ai_round<3>(Us, Ws, tab + Lay::AI_AB, kg + 4 * NL, L.odd, K, cm);
+                coop_ai_round<4>(Us, Ws, tab + Lay::AI_AB, kg + 6 * NL, L.odd, K, cm);
+                coop_ai_round<0>(Us, Ws, tab + Lay::AI_AB, kg + 8 * NL, L.odd, K, cm);
             }
+            coop_load_kappa(L.kap, tab, RF, L.row);  // round 4's, hidden by the exit row and the S-box that follow
             const E29* const us[4] = {&Us[3], &Us[4], &Us[0], &Us[1]};
             const E29* const ws[4] = {&Ws[2], &Ws[3], &Ws[4], &Ws[0]};
             const E29 r = exit_row(us, ws, exn, exfix, exadd, K);
 #pragma unroll
-            for (int k = 0; k < NL; ++k) s.d[k] = lane < 4 ? r.d[k] : Us[1].d[k];  // lanes 0..3: my row; lane 4: U_61
+            for (int k = 0; k < NL; ++k) s.d[k] = L.lane < 4 ? r.d[k] : Us[1].d[k];  // lanes 0..3: my row; lane 4: U_61
             s4 = Us[1];
         }
     }
-    // the last linear layer: only row 1 is squeezed — every lane forms it (uniform constants), then the scale F
-    const E29 d = int_row(xs, tab + Lay::INT_N + 1, tab + Lay::AI_KAPPA + ((2 * RF - 1) * WIDTH + 1) * NL);
-    return mul_c(d, tab + Lay::AI_F);
+    // the scale F of the output (the last round's row was formed above; tight reduction: what to_mont4 expects)
+    s = mul_c(s, tab + Lay::AI_F);
+    if (LANES == 4 && ROW4) s4 = mul_c(s4, tab + Lay::AI_F);
 }
 
 }  // namespace p252

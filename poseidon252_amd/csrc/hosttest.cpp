@@ -167,22 +167,24 @@ struct HostComm {
     E29 swap1(const E29& v) { return exchange(v, j ^ 1); }
 };
 
-template <int LANES>
-void digest_coop_threads(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n) {
+// states[n][5] -> out[n][5] (DIGEST: only element 1 of each output is written, the rest left untouched)
+template <int LANES, bool DIGEST>
+void permute_coop_threads(const uint64_t* states, uint64_t* out, size_t n) {
     const int32_t* tab = tab29().data();
     HostGroup g;
     pthread_barrier_init(&g.bar, nullptr, LANES);
     std::vector<std::thread> th;
-    std::vector<uint64_t> res((size_t)LANES * n * 4);
+    constexpr int OWN = CoopLane<LANES>::OWN;
     for (int j = 0; j < LANES; ++j)
         th.emplace_back([&, j] {
             HostComm cm{&g, j};
-            for (size_t i = 0; i < n; ++i) {
-                const int el = LANES == 8 ? (j < WIDTH ? j : WIDTH - 1) : j;
-                const E29 mine = from_mont4(reinterpret_cast<const uint32_t*>(el == 0 ? tag : children + (i * 4 + el - 1) * 4));
-                const E29 last = from_mont4(reinterpret_cast<const uint32_t*>(children + (i * 4 + 3) * 4));
-                const E29 r = merkle4_digest_coop<LANES>(mine, last, tab, cm);
-                to_mont4(r, reinterpret_cast<uint32_t*>(res.data() + ((size_t)j * n + i) * 4));
+            CoopLane<LANES> L = coop_lane<LANES>(tab, cm);
+                for (size_t i = 0; i < n; ++i) {
+                E29 s = from_mont4(reinterpret_cast<const uint32_t*>(states + (i * 5 + L.row) * 4));
+                E29 s4 = from_mont4(reinterpret_cast<const uint32_t*>(states + (i * 5 + 4) * 4));
+                hades_permute_coop<LANES, !DIGEST>(s, s4, tab, cm, L);
+                if (j < OWN && (!DIGEST || j == 1)) to_mont4(s, reinterpret_cast<uint32_t*>(out + (i * 5 + j) * 4));
+                if (LANES == 4 && j == 0 && !DIGEST) to_mont4(s4, reinterpret_cast<uint32_t*>(out + (i * 5 + 4) * 4));
             }
 #if defined(P252_TRACK_BOUNDS)
             std::lock_guard<std::mutex> lk(g.mu);
@@ -200,27 +202,34 @@ void digest_coop_threads(const uint64_t* tag, const uint64_t* children, uint64_t
     if (g.merged.max_top > b.max_top) b.max_top = g.merged.max_top;
     if (g.merged.max_top1 > b.max_top1) b.max_top1 = g.merged.max_top1;
 #endif
-    // every lane must hold the same digest; lane 0's is returned, a disagreement is reported as all-ones
-    for (size_t i = 0; i < n; ++i) {
-        bool same = true;
-        for (int j = 1; j < LANES; ++j) same = same && std::memcmp(&res[((size_t)j * n + i) * 4], &res[i * 4], 32) == 0;
-        if (same)
-            std::memcpy(out + i * 4, &res[i * 4], 32);
-        else
-            std::memset(out + i * 4, 0xff, 32);
-    }
 }
 }  // namespace
 }  // extern "C++"
 
 // lanes = 8 or 4 (the two group sizes of coop29.hpp); returns 0, or -1 for any other value
-int ht_merkle4_digest_coop(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n, int lanes) {
+int ht_permute_coop(const uint64_t* states, uint64_t* out, size_t n, int lanes) {
     if (lanes == 8)
-        digest_coop_threads<8>(tag, children, out, n);
+        permute_coop_threads<8, false>(states, out, n);
     else if (lanes == 4)
-        digest_coop_threads<4>(tag, children, out, n);
+        permute_coop_threads<4, false>(states, out, n);
     else
         return -1;
+    return 0;
+}
+// the Merkle4 digest as the cooperative kernels form it: state [tag, c0..c3], element 1 of the result
+int ht_merkle4_digest_coop(const uint64_t* tag, const uint64_t* children, uint64_t* out, size_t n, int lanes) {
+    std::vector<uint64_t> st(n * 20), res(n * 20, ~0ull);
+    for (size_t i = 0; i < n; ++i) {
+        std::memcpy(&st[i * 20], tag, 32);
+        std::memcpy(&st[i * 20 + 4], children + i * 16, 128);
+    }
+    if (lanes == 8)
+        permute_coop_threads<8, true>(st.data(), res.data(), n);
+    else if (lanes == 4)
+        permute_coop_threads<4, true>(st.data(), res.data(), n);
+    else
+        return -1;
+    for (size_t i = 0; i < n; ++i) std::memcpy(out + i * 4, &res[i * 20 + 4], 32);
     return 0;
 }
 

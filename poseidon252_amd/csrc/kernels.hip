@@ -193,16 +193,100 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __re
 #pragma unroll
         for (int k = 0; k < NL; ++k) mine.d[k] = el > 0 ? child.d[k] : mine.d[k];
     }
-    E29 r;
+    E29 last = mine;
+    if (LANES == 4) last = load_child_or_zero(children, n_children, idx, arity, 3);  // element 4 travels on every lane
     if (LANES == 8) {
         WaveComm8 cm{j, (int)(((threadIdx.x & 63u) & ~7u) * 4u)};
-        r = merkle4_digest_coop<8>(mine, mine, tab, cm);
+        CoopLane<8> L = coop_lane<8>(tab, cm);
+        hades_permute_coop<8, false>(mine, last, tab, cm, L);
     } else {
-        const E29 last = load_child_or_zero(children, n_children, idx, arity, 3);  // element 4 travels on every lane
         WaveComm4 cm{j};
-        r = merkle4_digest_coop<4>(mine, last, tab, cm);
+        CoopLane<4> L = coop_lane<4>(tab, cm);
+        hades_permute_coop<4, false>(mine, last, tab, cm, L);
     }
-    if (j == 0) store_scalar(out + idx, r);
+    if (j == 1) store_scalar(out + idx, mine);  // the digest is element 1 of the permuted state: lane 1's
+}
+
+// ---- the other entry points for batches that cannot fill the chip (n <= 8,192): the same 8-lane groups, lane i holding
+// state element i throughout.  Bit-identical results to the one-lane kernels below (P252_COOP_MAX_NODES=0 selects those). ----
+__global__ void __launch_bounds__(P252_BLOCK) k_permute_coop(const int32_t* __restrict__ tab, const Scalar32* __restrict__ in,
+                                                             Scalar32* __restrict__ out, size_t n) {
+    const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    const size_t idx = lane / 8;
+    if (idx >= n) return;
+    const int j = (int)(threadIdx.x & 7u);
+    WaveComm8 cm{j, (int)(((threadIdx.x & 63u) & ~7u) * 4u)};
+    CoopLane<8> L = coop_lane<8>(tab, cm);
+    E29 s = load_scalar(in + idx * WIDTH + L.row), unused = s;
+    // (a loop of one iteration, as k_sponge_coop's loop of several: with the call in the kernel's entry block the register
+    // allocator ends at 256 VGPRs + 4 AGPRs instead of 212)
+#pragma unroll 1
+    for (int once = 0; once < 1; ++once) hades_permute_coop<8>(s, unused, tab, cm, L);
+    if (j < WIDTH) store_scalar(out + idx * WIDTH + j, s);
+}
+
+// the sponge of k_sponge with the state spread over a group: lane 0 the capacity element, lanes 1..4 the rate
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge_coop(const int32_t* __restrict__ tab, TagArg tag,
+                                                            const Scalar32* __restrict__ in, unsigned in_len,
+                                                            unsigned out_len, Scalar32* __restrict__ out, size_t n) {
+    const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    const size_t idx = lane / 8;
+    if (idx >= n) return;
+    const int j = (int)(threadIdx.x & 7u);
+    WaveComm8 cm{j, (int)(((threadIdx.x & 63u) & ~7u) * 4u)};
+    CoopLane<8> L = coop_lane<8>(tab, cm);
+    const Scalar32* my_in = in + idx * in_len;
+    Scalar32* my_out = out + idx * out_len;
+    const unsigned slot = (unsigned)L.row - 1u;  // my position in the rate (lane 0: none; lanes 5..7 shadow lane 4)
+    const bool rate = L.row > 0;
+    E29 s = from_mont4(tag.w), unused;
+    if (rate) s = slot < in_len ? load_scalar(my_in + slot) : e29_zero();  // block 0 of the message
+    unused = s;
+    const unsigned absorb_blocks = (in_len + 3) / 4;
+    const unsigned squeeze_blocks = (out_len + 3) / 4;
+#pragma unroll 1
+    for (unsigned it = 1; it < absorb_blocks + squeeze_blocks; ++it) {
+        hades_permute_coop<8>(s, unused, tab, cm, L);
+        if (it < absorb_blocks) {
+            const unsigned e = it * 4 + slot;
+            if (rate && e < in_len) add_e(s, load_scalar(my_in + e));  // Safe::add, scalar.rs:33-35
+        } else {
+            const unsigned o = (it - absorb_blocks) * 4 + slot;
+            if (rate && j < WIDTH && o < out_len) store_scalar(my_out + o, s);
+        }
+    }
+}
+
+// the opening of k_merkle4_path on a group: lane 0 the tag, lane 1 + slot the child in that slot of the node
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path_coop(const int32_t* __restrict__ tab, TagArg tag,
+                                                                  const Scalar32* __restrict__ leaves,
+                                                                  const Scalar32* __restrict__ siblings,
+                                                                  const uint8_t* __restrict__ positions, unsigned depth,
+                                                                  Scalar32* __restrict__ roots, size_t n) {
+    const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    const size_t idx = lane / 8;
+    if (idx >= n) return;
+    const int j = (int)(threadIdx.x & 7u);
+    WaveComm8 cm{j, (int)(((threadIdx.x & 63u) & ~7u) * 4u)};
+    CoopLane<8> L = coop_lane<8>(tab, cm);
+    const E29 t = from_mont4(tag.w);
+    E29 cur = load_scalar(leaves + idx);
+    const Scalar32* sib = siblings + idx * depth * 3;
+    const uint8_t* pos = positions + idx * depth;
+    const unsigned slot = (unsigned)L.row - 1u;
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; ++l) {
+        const unsigned p = pos[l] & 3u;
+        // children = the three siblings in order with `cur` inserted at slot p
+        E29 s = t, unused;
+        if (L.row > 0 && slot != p) s = load_scalar(sib + l * 3 + (slot < p ? slot : slot - 1));
+#pragma unroll
+        for (int k = 0; k < NL; ++k) s.d[k] = (L.row > 0 && slot == p) ? cur.d[k] : s.d[k];
+        unused = s;
+        hades_permute_coop<8, false>(s, unused, tab, cm, L);
+        cur = cm.get<1>(s);  // the digest, to every lane
+    }
+    if (j == 0) store_scalar(roots + idx, cur);
 }
 
 // ---- generic sponge: n messages, same (in_len, out_len).  dusk-safe mechanics:
@@ -400,8 +484,24 @@ namespace p252 {
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + P252_BLOCK - 1) / P252_BLOCK); }
 
+// largest batch that runs on the cooperative (several lanes per state) kernels: P252_COOP_MAX_NODES, default 16384
+// (8 lanes per state up to 8,192 — every entry point; 4 lanes up to 16,384 — Merkle digests only); 0 = never
+static size_t coop_max_nodes() {
+    static const size_t v = [] {
+        const char* e = std::getenv("P252_COOP_MAX_NODES");
+        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)16384;
+    }();
+    return v;
+}
+static inline bool coop8(size_t n) { return n <= coop_max_nodes() && n * 8 <= (size_t)65536; }
+
 hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    if (coop8(n)) {
+        hipLaunchKernelGGL(k_permute_coop, dim3(grid_for(n * 8)), dim3(P252_BLOCK), 0, st, tab,
+                           static_cast<const Scalar32*>(in), static_cast<Scalar32*>(out), n);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_permute, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab,
                        static_cast<const Scalar32*>(in), static_cast<Scalar32*>(out), n);
     return hipGetLastError();
@@ -411,12 +511,7 @@ hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* chi
                           void* out, size_t n, hipStream_t st, unsigned arity, size_t pad_lanes) {
     if (n == 0) return hipSuccess;
     // launches of at most one wave per SIMD with 8 (4) lanes per node: the cooperative low-latency builds
-    // (P252_COOP_MAX_NODES: largest launch that may use them, default 16384; 0 = never)
-    static const size_t coop_max = [] {
-        const char* e = std::getenv("P252_COOP_MAX_NODES");
-        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)16384;
-    }();
-    if (n <= coop_max && n * 4 <= (size_t)65536) {
+    if (n <= coop_max_nodes() && n * 4 <= (size_t)65536) {
         const bool eight = n * 8 <= (size_t)65536;
         const size_t want = n * (eight ? 8 : 4);
         const size_t lanes = want < pad_lanes ? pad_lanes : want;
@@ -454,6 +549,11 @@ hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* chi
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
                          unsigned out_len, void* out, size_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    if (coop8(n)) {
+        hipLaunchKernelGGL(k_sponge_coop, dim3(grid_for(n * 8)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_sponge, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                        static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
     return hipGetLastError();
@@ -486,6 +586,12 @@ hipError_t launch_truncate250(const void* in, void* out, size_t n, hipStream_t s
 hipError_t launch_merkle4_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings,
                                const void* positions, unsigned depth, void* roots, size_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    if (coop8(n)) {
+        hipLaunchKernelGGL(k_merkle4_path_coop, dim3(grid_for(n * 8)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(leaves), static_cast<const Scalar32*>(siblings),
+                           static_cast<const uint8_t*>(positions), depth, static_cast<Scalar32*>(roots), n);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_merkle4_path, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                        static_cast<const Scalar32*>(leaves), static_cast<const Scalar32*>(siblings),
                        static_cast<const uint8_t*>(positions), depth, static_cast<Scalar32*>(roots), n);

@@ -46,6 +46,35 @@ def test_trees_whose_levels_run_on_the_cooperative_kernel(gpu_ctx, oracle_mod, n
     assert np.array_equal(root, o_root) and np.array_equal(levels, o_levels)
 
 
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 300, 8191, 8192, 8193])
+def test_permute_sponge_and_openings_on_lane_groups(gpu_ctx, oracle_mod, n):
+    """batches of <= 8,192 run k_permute_coop / k_sponge_coop / k_merkle4_path_coop (lane i of a group holds state element
+    i); 8,193 is the first size on the one-lane kernels"""
+    st = oracle_mod.fill_random(11 + n, 5 * n).reshape(n, 5, 4)
+    assert np.array_equal(gpu_ctx.permute_batch(st), oracle_mod.permute_batch(st))
+    tag = oracle_mod.fill_random(3, 1).reshape(4)
+    m = min(n, 1200)  # (the oracle is the slow side)
+    for in_len, out_len in ((1, 1), (3, 3), (4, 7), (5, 2), (9, 6), (42, 5)):
+        msg = oracle_mod.fill_random(100 * in_len + out_len + n, m * in_len).reshape(m, in_len, 4)
+        assert np.array_equal(gpu_ctx.hash_batch(tag, msg, in_len, out_len), oracle_mod.hash_batch(tag, msg, in_len, out_len, threads=8)), (in_len, out_len)
+    mtag = oracle_mod.tag(0, [4], 1)
+    rng = np.random.default_rng(n)
+    for depth in (0, 1, 5, 12):
+        leaves = oracle_mod.fill_random(7 * n + depth, m)
+        sib = oracle_mod.fill_random(9 * n + depth, m * depth * 3).reshape(m, depth, 3, 4) if depth else np.zeros((m, 0, 3, 4), dtype=np.uint64)
+        pos = rng.integers(0, 4, size=(m, depth), dtype=np.uint8)
+        assert np.array_equal(gpu_ctx.merkle4_path_batch(mtag, leaves, sib, pos), oracle_mod.merkle4_path_batch(mtag, leaves, sib, pos)), depth
+
+
+def test_one_lane_kernels_still_pass_the_parity_suite():
+    """the parity suite's batches are small: by default they run on the lane-group kernels (the reference's six KAT digests
+    through k_sponge_coop, for one).  With P252_COOP_MAX_NODES=0 the same suite runs on the one-lane kernels again."""
+    env = dict(os.environ, P252_COOP_MAX_NODES="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_next_rows.py"),
+                        "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=os.path.dirname(HERE), env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:] + r.stderr.decode()[-2000:]
+
+
 def test_same_bytes_as_the_one_lane_kernels():
     """P252_COOP_MAX_NODES=0 (read once per process, hence the subprocesses) sends every launch to the one-lane kernels:
     digests and tree levels must be the same bytes either way"""
@@ -59,6 +88,11 @@ for n in (1, 9, 300, 8192, 12000):
     h.update(ctx.hash_batch(tag, x, 4, 1).tobytes())
 root, levels = P.merkle4_tree(oracle.fill_random(9, 70001), tag=tag, ctx=ctx, want_levels=True)
 h.update(root.tobytes()); h.update(levels.tobytes())
+st = oracle.fill_random(5, 5 * 3000).reshape(3000, 5, 4)
+h.update(ctx.permute_batch(st).tobytes())
+h.update(ctx.hash_batch(st[0, 0], st.reshape(-1, 4)[:42 * 300].reshape(300, 42, 4), 42, 5).tobytes())
+pos = (np.arange(2000 * 6) % 4).astype(np.uint8).reshape(2000, 6)
+h.update(ctx.merkle4_path_batch(tag, st[:2000, 0], oracle.fill_random(8, 2000 * 18).reshape(2000, 6, 3, 4), pos).tobytes())
 print("DIGEST", h.hexdigest())
 '''
     outs = []

@@ -258,9 +258,10 @@ def test_digest_path_with_hoisted_tag_sbox(oracle_mod, hosttest_lib):
 
 @pytest.mark.parametrize("lanes", [8, 4])
 def test_cooperative_digest_lane_groups(oracle_mod, hosttest_lib, lanes):
-    """coop29.hpp — one digest computed by a group of eight (or four) lanes (the low-latency kernels k_merkle4_coop<8|4>),
-    with the lanes played by host threads and the cross-lane exchange by a barrier: every lane returns the oracle's digest
-    for random, edge and non-canonical children and tags, and the reductions stay inside the same column / digit bounds."""
+    """coop29.hpp — one permutation computed by a group of eight (or four) lanes (the low-latency kernels), with the lanes
+    played by host threads and the cross-lane exchange by a barrier: the digest form (k_merkle4_coop<8|4>) and the full
+    five-element permutation equal the oracle's for random, edge and non-canonical inputs, and the reductions stay inside
+    the same column / digit bounds."""
     import math
     for f in (hosttest_lib.ht_bounds_max_col, hosttest_lib.ht_bounds_max_top, hosttest_lib.ht_bounds_max_top1):
         f.restype = ctypes.c_double
@@ -284,6 +285,12 @@ def test_cooperative_digest_lane_groups(oracle_mod, hosttest_lib, lanes):
     hosttest_lib.ht_merkle4_digest_coop(p(tag), p(raw), p(a), 12, lanes)
     hosttest_lib.ht_merkle4_digest_coop(p(tag), p(red), p(b), 12, lanes)
     assert np.array_equal(a, b) and np.array_equal(b, oracle_mod.hash_batch(tag, red, 4, 1).reshape(12, 4))
+    # the full permutation: lane i returns element i (4 lanes: element 4 rides on every lane)
+    st = np.concatenate([oracle_mod.fill_random(99, 5 * 60).reshape(60, 5, 4), edge[:15].reshape(3, 5, 4),
+                         np.array([[oracle_mod.int_to_limbs(pats[(i + k) % len(pats)] % P) for k in range(5)] for i in range(6)], dtype=np.uint64)])
+    got = np.empty_like(st)
+    assert hosttest_lib.ht_permute_coop(p(st), p(got), st.shape[0], lanes) == 0
+    assert np.array_equal(got, oracle_mod.permute_batch(st))
     col, top = hosttest_lib.ht_bounds_max_col(), hosttest_lib.ht_bounds_max_top()
     if col >= 0:
         assert 2 ** 58 < col < 2 ** 62.6, math.log2(col)

@@ -36,7 +36,9 @@ def test_no_scratch_and_register_budget(isa):
         assert s == 0, "%s uses %d B of scratch per lane (an unroll fell back to a loop?)" % (n, s)
         # 256 VGPRs + spills into AGPRs = one wave per SIMD: measured -18 % on the sponge kernel (the scheduler had
         # interleaved independent rows and carried the history rings through the full-round loop)
-        assert a == 0 and v < 256 and o >= 2, "%s: %d VGPRs + %d AGPRs, %d waves/SIMD" % (n, v, a, o)
+        # (the lane-group kernels *_coop only ever run at one wave per SIMD: any register count without spills will do)
+        assert a == 0 and v <= 256 and (o >= 2 or "_coop" in n), "%s: %d VGPRs + %d AGPRs, %d waves/SIMD" % (n, v, a, o)
+        assert "_coop" in n or v < 256, "%s: %d VGPRs" % (n, v)
         # the throughput builds of the single-digest kernels are held at 3 waves per SIMD (amdgpu_waves_per_eu): left
         # alone the allocator lands at 169 VGPRs = 2 waves, -1.2 % on 2^20 digests (profiles/r02_ab_occupancy.txt)
         if re.search(r"\d+k_merkle4E|k_merkle4_pathE", n):
