@@ -444,14 +444,17 @@ def main():
         achieved_mac = per_gpu_rate * MACS_PER_PERM_REFERENCE
         hbm_gbps = per_gpu_rate * BYTES_PER_PERM[wl] / 1e9
         kern = KERNEL_OF[wl]
-        lanes_per_perm = 1
+        lanes_per_perm, isa_key, pmc_key = 1, None, None
         coop_max = int(os.environ.get("P252_COOP_MAX_NODES", "16384"))
-        if wl == "merkle4_digests" and 8192 < perms_per_step <= min(coop_max, 16384):
-            kern, lanes_per_perm = "k_merkle4_coop<4>", 4
-        elif wl == "merkle4_digests" and perms_per_step <= min(coop_max, 8192):
-            # launches this small run the cooperative low-latency kernel: eight lanes per digest (csrc/coop29.hpp)
-            kern, lanes_per_perm = "k_merkle4_coop<8>", 8
-        isa = isa_counts(kern)
+        items = n  # independent states per launch (digests, messages, openings)
+        if wl == "merkle4_digests" and 8192 < items <= min(coop_max, 16384):
+            kern, lanes_per_perm, isa_key, pmc_key = "k_merkle4_coop<4>", 4, "k_merkle4_coop<4>", "k_merkle4_coop4"
+        elif wl in ("merkle4_digests", "sponge42", "openings") and items <= min(coop_max, 8192):
+            # batches this small run the lane-group kernels: eight lanes per state (csrc/coop29.hpp); the permutation body is
+            # the one of k_merkle4_coop<8>, whose ISA counts and counter passes stand for all of them
+            kern = {"merkle4_digests": "k_merkle4_coop<8>", "sponge42": "k_sponge_coop", "openings": "k_merkle4_path_coop"}[wl]
+            lanes_per_perm, isa_key, pmc_key = 8, "k_merkle4_coop<8>", "k_merkle4_coop8"
+        isa = isa_counts(isa_key or kern)
         executed = issue = None
         if isa:
             mac_rate = per_gpu_rate * lanes_per_perm * isa["v_mad_i64_i32"]
@@ -463,7 +466,7 @@ def main():
             # 3-operand forms, 2 for plain 32-bit ops — profiles/r02_valu_rates_gfx950.txt): share of all SIMD cycles
             cyc = per_gpu_rate * lanes_per_perm / 64.0 * isa["valu_issue_cycles"]
             issue = {"valu_insts_per_perm": isa["valu_total"], "lanes_per_perm": lanes_per_perm, "issue_cycles_per_perm": isa["valu_issue_cycles"],
-                     "frac": cyc / (SIMDS * NOMINAL_CLOCK_HZ), "pmc": pmc_valu(kern),
+                     "frac": cyc / (SIMDS * NOMINAL_CLOCK_HZ), "pmc": pmc_valu(pmc_key or kern),
                      "note": "SIMD cycles spent issuing VALU work under the 4-/2-cycle model / all SIMD cycles at 2.4 GHz"}
         roofline = {
             "bound": "valu-int32-mac", "kernel": kern,
@@ -476,7 +479,7 @@ def main():
             "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
             "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
                     "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
-            "traffic": pmc_traffic(kern, wl, perms_per_step),
+            "traffic": pmc_traffic(pmc_key or kern, wl, perms_per_step),
         }
         line = {
             "metric": "Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact",

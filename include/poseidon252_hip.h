@@ -30,6 +30,10 @@
  * wrapper raises.  There is NO CPU fallback: without a usable HIP device every compute entry point
  * fails with P252_ERR_NO_DEVICE / P252_ERR_HIP.
  *
+ * Batch size: any n >= 0.  A batch of at most 8,192 items (16,384 Merkle digests) cannot fill the chip and is bound by
+ * one wave's latency; such batches run kernels that spread each state over a group of lanes (0.12 ms per permutation
+ * instead of 0.17).  Results are the same bytes whichever kernel runs.
+ *
  * Threading: a context is bound to one device and used by one thread at a time; distinct contexts
  * are independent.  Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
  * or the p252_*_multi entry points below, which take the array of contexts and shard inside the library; batches
