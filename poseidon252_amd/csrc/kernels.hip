@@ -419,6 +419,75 @@ __global__ void __launch_bounds__(P252_BLOCK) k_crypt(const int32_t* __restrict_
     }
 }
 
+// k_crypt on lane groups (batches of <= 8,192 messages): lane 0 the capacity element, lane 1 + pos the rate position pos.
+// Every position is wave-uniform, so "the lane at this position" is one compare; a message element decrypted by one
+// lane and absorbed later by another travels through `out` (same wave, program order: the pointer is not __restrict__).
+template <bool DECRYPT>
+__global__ void __launch_bounds__(P252_BLOCK) k_crypt_coop(const int32_t* __restrict__ tab, TagArg tag,
+                                                           const Scalar32* __restrict__ in,
+                                                           const Scalar32* __restrict__ secrets,
+                                                           const Scalar32* __restrict__ nonces, unsigned len,
+                                                           Scalar32* out, uint8_t* __restrict__ flags, size_t n,
+                                                           const uint32_t* __restrict__ prog, unsigned n_calls) {
+    const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    const size_t idx = lane / 8;
+    if (idx >= n) return;
+    const int j = (int)(threadIdx.x & 7u);
+    WaveComm8 cm{j, (int)(((threadIdx.x & 63u) & ~7u) * 4u)};
+    CoopLane<8> L = coop_lane<8>(tab, cm);
+    const Scalar32* my_in = in + idx * (DECRYPT ? len + 1 : len);
+    Scalar32* my_out = out + idx * (DECRYPT ? len : len + 1);
+    E29 s = from_mont4(tag.w), unused;
+    if (L.row > 0) s = e29_zero();
+    unused = s;
+    unsigned pos_absorb = 0, pos_squeeze = 0, masked = 0, absorbed = 0;
+#pragma unroll 1
+    for (unsigned ci = 0; ci < n_calls; ++ci) {
+        const unsigned kind = prog[ci] >> 29, cnt = prog[ci] & 0x1fffffffu;
+        const bool is_absorb = kind == 0 || kind == 1 || kind == 3;
+#pragma unroll 1
+        for (unsigned e = 0; e < cnt; ++e) {
+            if ((is_absorb ? pos_absorb : pos_squeeze) == 4) {
+                hades_permute_coop<8>(s, unused, tab, cm, L);
+                pos_absorb = 0;
+                if (!is_absorb) pos_squeeze = 0;
+            }
+            if (is_absorb) {
+                const Scalar32* src = kind == 0 ? secrets + 2 * idx + e
+                                      : kind == 1 ? nonces + idx
+                                                  : (DECRYPT ? my_out : my_in) + absorbed + e;
+                if (L.row == (int)(1 + pos_absorb)) add_e(s, load_scalar(src));  // Safe::add, scalar.rs:33-35
+                ++pos_absorb;
+            } else {
+                const bool mine = j == (int)(1 + pos_squeeze);  // (the lane itself, not its shadows: one store per element)
+                ++pos_squeeze;
+                if (!mine) continue;
+                if (kind == 2) {
+                    E29 x = load_scalar(my_in + masked + e);
+                    if (!DECRYPT)
+                        add_e(x, s);  // cipher = message + mask
+                    else
+                        sub_e(x, s);  // message = cipher - mask
+                    store_scalar(my_out + masked + e, x);
+                } else if (!DECRYPT) {
+                    store_scalar(my_out + len, s);
+                } else {
+                    uint32_t w[8];
+                    to_mont4(s, w);
+                    const uint4 lo = *reinterpret_cast<const uint4*>(my_in + len);
+                    const uint4 hi = *(reinterpret_cast<const uint4*>(my_in + len) + 1);
+                    const bool same = w[0] == lo.x && w[1] == lo.y && w[2] == lo.z && w[3] == lo.w && w[4] == hi.x &&
+                                      w[5] == hi.y && w[6] == hi.z && w[7] == hi.w;
+                    flags[idx] = same ? 1 : 0;
+                }
+            }
+        }
+        if (is_absorb) pos_squeeze = 4;
+        if (kind == 2) masked += cnt;
+        if (kind == 3) absorbed += cnt;
+    }
+}
+
 // ---- finalize_truncated post-processing (hash.rs:164-183) on device-resident digests:
 // canonical value (Montgomery form dropped) & (2^250 - 1), written as the raw limbs that
 // JubJubScalar::from_raw receives.  redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256 = the canonical value. ----
@@ -563,6 +632,19 @@ hipError_t launch_crypt(bool decrypt, const int32_t* tab, const TagArg& tag, con
                         const void* nonces, unsigned len, void* out, void* flags, size_t n, const uint32_t* prog,
                         unsigned n_calls, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    if (coop8(n)) {
+        if (decrypt)
+            hipLaunchKernelGGL(k_crypt_coop<true>, dim3(grid_for(n * 8)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(in), static_cast<const Scalar32*>(secrets),
+                               static_cast<const Scalar32*>(nonces), len, static_cast<Scalar32*>(out),
+                               static_cast<uint8_t*>(flags), n, prog, n_calls);
+        else
+            hipLaunchKernelGGL(k_crypt_coop<false>, dim3(grid_for(n * 8)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(in), static_cast<const Scalar32*>(secrets),
+                               static_cast<const Scalar32*>(nonces), len, static_cast<Scalar32*>(out),
+                               static_cast<uint8_t*>(flags), n, prog, n_calls);
+        return hipGetLastError();
+    }
     if (decrypt)
         hipLaunchKernelGGL(k_crypt<true>, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                            static_cast<const Scalar32*>(in), static_cast<const Scalar32*>(secrets),

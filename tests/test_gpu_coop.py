@@ -66,11 +66,32 @@ def test_permute_sponge_and_openings_on_lane_groups(gpu_ctx, oracle_mod, n):
         assert np.array_equal(gpu_ctx.merkle4_path_batch(mtag, leaves, sib, pos), oracle_mod.merkle4_path_batch(mtag, leaves, sib, pos)), depth
 
 
+@pytest.mark.parametrize("n", [1, 9, 700, 8192, 8193])
+@pytest.mark.parametrize("length", [1, 2, 4, 5, 21, 42])
+def test_encryption_on_lane_groups(gpu_ctx, oracle_mod, n, length):
+    """k_crypt_coop (<= 8,192 messages): ciphers equal the oracle's under both call sequences, decryption restores the
+    messages (a plaintext element decrypted by one lane is absorbed by another), a flipped limb fails the MAC"""
+    from poseidon252_amd import encryption as E
+    m = min(n, 400 if length > 5 else n)
+    msg = oracle_mod.fill_random(length * 1000 + n, m * length).reshape(m, length, 4)
+    sec = oracle_mod.fill_random(length * 1000 + n + 1, m * 2).reshape(m, 2, 4)
+    non = oracle_mod.fill_random(length * 1000 + n + 2, m)
+    for variant in (E.STREAM, E.DUPLEX):
+        c = E.encrypt_batch(msg, sec, non, ctx=gpu_ctx, variant=variant)
+        assert np.array_equal(c, oracle_mod.encrypt_batch(E.encryption_tag(length, variant), msg, sec, non, variant=variant))
+        back, ok = E.decrypt_batch(c, sec, non, ctx=gpu_ctx, variant=variant)
+        assert ok.all() and np.array_equal(back, msg)
+        bad = c.copy()
+        bad[m - 1, length // 2, 0] ^= np.uint64(1)
+        _, ok2 = E.decrypt_batch(bad, sec, non, ctx=gpu_ctx, variant=variant)
+        assert not ok2[m - 1] and ok2[:m - 1].all()
+
+
 def test_one_lane_kernels_still_pass_the_parity_suite():
     """the parity suite's batches are small: by default they run on the lane-group kernels (the reference's six KAT digests
     through k_sponge_coop, for one).  With P252_COOP_MAX_NODES=0 the same suite runs on the one-lane kernels again."""
     env = dict(os.environ, P252_COOP_MAX_NODES="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_next_rows.py"),
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_next_rows.py"), os.path.join(HERE, "test_encryption.py"),
                         "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=os.path.dirname(HERE), env=env, capture_output=True, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-3000:] + r.stderr.decode()[-2000:]
 
