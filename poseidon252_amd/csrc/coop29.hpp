@@ -1,4 +1,4 @@
-// coop29.hpp — ONE Merkle4 digest computed by a group of 8 lanes: the low-latency build of the permutation.
+// coop29.hpp — ONE permutation computed by a group of 8 (or 4) lanes: the low-latency build (kernels *_coop of kernels.hip).
 //
 // Why: a permutation is ~80 k dependent instructions for the lane that runs it, so a launch of at most one wave per SIMD
 // (a tree's levels of <= 65,536 nodes, small batches) takes 0.165 ms whatever its size.  Such launches
@@ -10,8 +10,10 @@
 //                 one exchange, then both form x^4 * (x G_q) — the same bits on both, so every lane carries the
 //                 complete history and the recurrence needs no exchange          3 sequential products instead of 4
 //   exit          the four exit rows run on four lanes (and land where the next full round wants them)   1 instead of 4
-// Sequential generic products per digest: 8 x 3 + 3 + 60 x 3 + 1 + 1 = 209 (one lane: 365).  Everything else — the
-// entry rows, the recurrence — is computed redundantly by all lanes, uniformly, with the constants in SGPRs as before.
+// Sequential generic products per permutation: 8 x 3 + 3 + 60 x 3 + 1 + 1 = 209 (one lane: 365; the last 1 is the output
+// scale F, one product per lane = per output element).  Everything else — the entry rows, the recurrence — is computed
+// redundantly by all lanes, uniformly, with the constants in SGPRs as before.  Lane i ends up with element i of the
+// permuted state, so a sponge keeps its state spread over the group from permutation to permutation.
 //
 // All arithmetic is the single-lane code of fr29.hpp / hades29.hpp (same tables, same reductions); the values are the
 // same residues, in places in a different lazy representative, and the result is canonicalised by to_mont4 as always.
@@ -27,7 +29,6 @@
 #include "hades29.hpp"
 
 namespace p252 {
-
 
 // x^5 G / R'^5 on a pair of lanes (odd = true for the odd lane).  g = the nine digits of G_q (wave-uniform).
 template <class Comm, class TP>
