@@ -12,9 +12,10 @@ for wl in tree sponge42 openings encrypt; do python bench.py --workload $wl --no
 python bench.py --log2n 12 --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_small4096.json 2>/dev/null
 python bench.py --log2n 14 --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_small16384.json 2>/dev/null
 python bench.py --log2n 24 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_2pow24_digests.json 2>/dev/null
+for wl in sponge42 openings encrypt; do python bench.py --workload $wl --log2n 12 --steps 60 --warmup 6 --no-cpu-baseline > $O/bench_${wl}_4096.json 2>/dev/null; done
 python - <<PY
 import json
-for f in ("bench","bench_tree","bench_sponge42","bench_openings","bench_encrypt","bench_small4096","bench_small16384","bench_2pow24_digests"):
+for f in ("bench","bench_tree","bench_sponge42","bench_openings","bench_encrypt","bench_small4096","bench_small16384","bench_2pow24_digests","bench_sponge42_4096","bench_openings_4096","bench_encrypt_4096"):
     try:
         d=json.loads(open("$O/%s.json"%f).readline())
         print("%-22s %.4g perm/s  %.4f ms/step  launch mean %.4f  kernel %s executed.frac %s"%(f,d["value"],d["ms_per_step"],d["roofline"]["launch_ms_mean"],d["roofline"]["kernel"],(d["roofline"]["executed"] or {}).get("frac")))
