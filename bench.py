@@ -449,10 +449,10 @@ def main():
         items = n  # independent states per launch (digests, messages, openings)
         if wl == "merkle4_digests" and 8192 < items <= min(coop_max, 16384):
             kern, lanes_per_perm, isa_key, pmc_key = "k_merkle4_coop<4>", 4, "k_merkle4_coop<4>", "k_merkle4_coop4"
-        elif wl in ("merkle4_digests", "sponge42", "openings") and items <= min(coop_max, 8192):
+        elif wl in ("merkle4_digests", "sponge42", "openings", "encrypt") and items <= min(coop_max, 8192):
             # batches this small run the lane-group kernels: eight lanes per state (csrc/coop29.hpp); the permutation body is
             # the one of k_merkle4_coop<8>, whose ISA counts and counter passes stand for all of them
-            kern = {"merkle4_digests": "k_merkle4_coop<8>", "sponge42": "k_sponge_coop", "openings": "k_merkle4_path_coop"}[wl]
+            kern = {"merkle4_digests": "k_merkle4_coop<8>", "sponge42": "k_sponge_coop", "openings": "k_merkle4_path_coop", "encrypt": "k_crypt_coop"}[wl]
             lanes_per_perm, isa_key, pmc_key = 8, "k_merkle4_coop<8>", "k_merkle4_coop8"
         isa = isa_counts(isa_key or kern)
         executed = issue = None

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_pad(const int32_t* __res
                                                             size_t n, unsigned arity, size_t lanes) {
     const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (lane >= lanes) return;
-    const size_t idx = lane % n;
+    const size_t idx = (unsigned)lane % (unsigned)n;  // (lanes < 2^31: the launcher sees to it — no 64-bit division)
     E29 s[WIDTH];
 #pragma unroll
     for (int k = 0; k < NL; ++k) s[0].d[k] = tag.x0[k];
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __re
                                                              size_t n, unsigned arity, size_t lanes) {
     const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (lane >= lanes) return;  // (lanes is a multiple of 8: whole groups only)
-    const size_t idx = (lane / LANES) % n;
+    const size_t idx = (unsigned)(lane / LANES) % (unsigned)n;  // (n <= 16,384 here: no 64-bit division)
     const int j = (int)(threadIdx.x & (LANES - 1));
     const int el = LANES == 8 ? (j < WIDTH ? j : WIDTH - 1) : j;  // the state element this lane brings: 0 = tag, 1..4 = children
     E29 mine = from_mont4(tag.w);
@@ -579,6 +579,7 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
                           void* out, size_t n, hipStream_t st, unsigned arity, size_t pad_lanes) {
     if (n == 0) return hipSuccess;
+    if (pad_lanes >= ((size_t)1 << 31)) pad_lanes = 0;  // (the padded kernels index with 32 bits)
     // launches of at most one wave per SIMD with 8 (4) lanes per node: the cooperative low-latency builds
     if (n <= coop_max_nodes() && n * 4 <= (size_t)65536) {
         const bool eight = n * 8 <= (size_t)65536;
