@@ -235,3 +235,22 @@ pub fn decrypt_batch(ctx: &Context, variant: c_int, ciphers: &[BlsScalar], messa
         .map(|i| if ok[i] == 1 { Ok(msgs[i * message_len..(i + 1) * message_len].to_vec()) } else { Err(Error::DecryptionFailed) })
         .collect())
 }
+
+/// `BlsScalar::to_bytes` for a slice: the 32 little-endian bytes of each canonical value (host-side twin of
+/// `p252_to_bytes_device`; the reference uses the pair at src/hades/round_constants.rs:66-67).
+pub fn to_bytes_batch(scalars: &[BlsScalar]) -> Vec<[u8; 32]> {
+    let mut out = vec![[0u8; 32]; scalars.len()];
+    let rc = unsafe { p252_to_bytes(scalars.as_ptr() as *const u64, out.as_mut_ptr() as *mut u8, scalars.len()) };
+    assert_eq!(rc, P252_OK);
+    out
+}
+
+/// `BlsScalar::from_bytes` for a slice of 32-byte records: `None` where the value is not below the modulus
+/// (`from_bytes` returns an error there).
+pub fn from_bytes_batch(bytes: &[[u8; 32]]) -> Vec<Option<BlsScalar>> {
+    let mut limbs = vec![BlsScalar::zero(); bytes.len()];
+    let mut ok = vec![0u8; bytes.len()];
+    let rc = unsafe { p252_from_bytes(bytes.as_ptr() as *const u8, limbs.as_mut_ptr() as *mut u64, ok.as_mut_ptr(), bytes.len()) };
+    assert_eq!(rc, P252_OK);
+    limbs.into_iter().zip(ok).map(|(s, o)| if o == 1 { Some(s) } else { None }).collect()
+}

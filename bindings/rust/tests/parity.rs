@@ -4,7 +4,8 @@
 //! 188-203, 277-292) plus the Merkle domains and BASELINE config 4, and tests/encryption.rs (message_len 42 and 21).
 use dusk_bls12_381::BlsScalar;
 use dusk_poseidon::{Domain, Hash};
-use dusk_poseidon_hip::{hash_tag, HashBatch};
+use dusk_bytes::Serializable;
+use dusk_poseidon_hip::{from_bytes_batch, hash_tag, to_bytes_batch, HashBatch};
 use ff::Field;
 use rand::rngs::StdRng;
 use rand::SeedableRng;
@@ -30,6 +31,24 @@ fn gpu_matches_reference_hash() {
 
 /// `Hash::update` chunks: the README example (README.md:31-44) hashes `[..3]` then `[3..]`; the digest must equal the
 /// one-chunk hash only if dusk-safe aggregates adjacent absorbs in the tag input — printed for the record.
+#[test]
+fn byte_format_matches_the_crate() {
+    // to_bytes / from_bytes of the real crate against the library's conversions (round_constants.rs:56-71 pattern)
+    let mut rng = StdRng::seed_from_u64(0xb17e5);
+    let xs: Vec<BlsScalar> = (0..1000).map(|_| BlsScalar::random(&mut rng)).collect();
+    let bytes = to_bytes_batch(&xs);
+    for (x, b) in xs.iter().zip(bytes.iter()) {
+        assert_eq!(&x.to_bytes(), b);
+    }
+    let back = from_bytes_batch(&bytes);
+    for (x, y) in xs.iter().zip(back.iter()) {
+        assert_eq!(Some(*x), *y);
+    }
+    // not below the modulus: an error in the crate, None here
+    assert_eq!(from_bytes_batch(&[[0xffu8; 32]]), vec![None]);
+    assert!(BlsScalar::from_bytes(&[0xffu8; 32]).is_err());
+}
+
 #[test]
 fn chunked_updates_and_the_tag_input_encoding() {
     let (t1, log1) = hash_tag(Domain::Other, &[42], 1).unwrap();

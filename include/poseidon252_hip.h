@@ -131,6 +131,13 @@ int p252_sync(p252_ctx* ctx, void* hip_stream);
  * value & (2^250 - 1), written as the raw limbs JubJubScalar::from_raw receives.  d_out_raw may alias
  * d_scalars. */
 int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_raw, size_t n, void* hip_stream);
+/* The canonical byte format on either side of the path: BlsScalar::to_bytes / from_bytes (dusk-bls12_381; the reference
+ * round-trips its round constants through the pair, src/hades/round_constants.rs:66-67, and reads its KAT inputs with
+ * from_hex_str, src/hades.rs:131).  bytes = n records of 32 little-endian bytes of the canonical value (16-byte aligned
+ * on the device).  from_bytes: ok[i] = 1 iff the value is < p — BlsScalar::from_bytes fails otherwise; the limbs written
+ * are then those of the value mod p; ok may be NULL.  Buffers may alias (in place). */
+int p252_to_bytes_device(p252_ctx* ctx, const void* d_scalars, void* d_bytes, size_t n, void* hip_stream);
+int p252_from_bytes_device(p252_ctx* ctx, const void* d_bytes, void* d_scalars, void* d_ok, size_t n, void* hip_stream);
 /* Batched Merkle openings (arity 4): recompute the root from a leaf and its sibling path — the branch
  * re-hash a `poseidon-merkle` verifier performs (AGENTS.md:62-66 names the downstream crate).  Per
  * level l, node = Hash::digest(Domain::Merkle4, children) where children[positions[l]] is the value
@@ -214,6 +221,10 @@ int p252_tag(int domain, const size_t* absorb_lens, size_t n_absorbs, size_t out
 /* finalize_truncated post-processing (hash.rs:164-183): canonical value & (2^250 - 1), as the raw
  * limbs handed to JubJubScalar::from_raw.  Host-side, n scalars. */
 int p252_truncate250(const uint64_t* scalars, uint64_t* out_raw, size_t n);
+
+/* host-side twins of p252_to_bytes_device / p252_from_bytes_device (no context, no GPU: one multiplication per scalar) */
+int p252_to_bytes(const uint64_t* scalars, uint8_t* bytes, size_t n);
+int p252_from_bytes(const uint8_t* bytes, uint64_t* scalars, uint8_t* ok, size_t n);
 
 /* library/version introspection */
 const char* p252_version(void);

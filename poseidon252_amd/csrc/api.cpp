@@ -694,6 +694,33 @@ int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_ra
     return P252_OK;
 }
 
+// ---- the canonical byte format of a scalar (BlsScalar::to_bytes / from_bytes; the reference round-trips its round
+// constants through the pair, src/hades/round_constants.rs:66-67, and reads its KAT inputs with from_hex_str, src/hades.rs:131)
+int p252_to_bytes_device(p252_ctx* ctx, const void* d_scalars, void* d_bytes, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!d_scalars || !d_bytes) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "to_bytes: NULL buffer");
+    if (misaligned(d_scalars) || misaligned(d_bytes)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_to_canonical(d_scalars, d_bytes, n, (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+int p252_from_bytes_device(p252_ctx* ctx, const void* d_bytes, void* d_scalars, void* d_ok, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!d_scalars || !d_bytes) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "from_bytes: NULL buffer");
+    if (misaligned(d_scalars) || misaligned(d_bytes)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
+    static const Digits9 r2 = [] {
+        Digits9 d;
+        encode_balanced29(FrHost::pow2(517), d.d);  // v * 2^517 / 2^261 = v * 2^256: the Montgomery form
+        return d;
+    }();
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_from_canonical(d_bytes, d_scalars, d_ok, n, r2, (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
 int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
                                    const void* d_positions, size_t depth, void* d_roots, size_t n, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
@@ -1091,6 +1118,29 @@ int p252_truncate250(const uint64_t* scalars, uint64_t* out_raw, size_t n) {  //
     for (size_t i = 0; i < n; ++i) {
         FrHost::from_limbs(scalars + 4 * i).to_canonical(out_raw + 4 * i);
         out_raw[4 * i + 3] &= 0x03ffffffffffffffULL;
+    }
+    return P252_OK;
+}
+
+// host-side twins of the two conversions (one Montgomery multiplication per scalar: not worth a transfer)
+int p252_to_bytes(const uint64_t* scalars, uint8_t* bytes, size_t n) {
+    if (n && (!scalars || !bytes)) return P252_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t c[4];
+        FrHost::from_limbs(scalars + 4 * i).to_canonical(c);
+        for (int k = 0; k < 32; ++k) bytes[32 * i + k] = (uint8_t)(c[k / 8] >> (8 * (k % 8)));
+    }
+    return P252_OK;
+}
+
+int p252_from_bytes(const uint8_t* bytes, uint64_t* scalars, uint8_t* ok, size_t n) {
+    if (n && (!bytes || !scalars)) return P252_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t v[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 32; ++k) v[k / 8] |= (uint64_t)bytes[32 * i + k] << (8 * (k % 8));
+        if (ok) ok[i] = FrHost::geq_p(v) ? 0 : 1;
+        while (FrHost::geq_p(v)) FrHost::sub_p(v);  // (a 256-bit value is below 3p)
+        std::memcpy(scalars + 4 * i, FrHost::from_raw(v).l, 32);
     }
     return P252_OK;
 }

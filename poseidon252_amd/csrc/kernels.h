@@ -30,6 +30,12 @@ hipError_t launch_crypt(bool decrypt, const int32_t* tab, const TagArg& tag, con
                         const void* nonces, unsigned len, void* out, void* flags, size_t n, const uint32_t* prog,
                         unsigned n_calls, hipStream_t st);
 hipError_t launch_truncate250(const void* in, void* out, size_t n, hipStream_t st);
+// canonical byte format (BlsScalar::to_bytes / from_bytes): r2 = the balanced digits of 2^517 mod p; ok may be null
+struct Digits9 {
+    int32_t d[9];
+};
+hipError_t launch_to_canonical(const void* in, void* out, size_t n, hipStream_t st);
+hipError_t launch_from_canonical(const void* in, void* out, void* ok, size_t n, const Digits9& r2, hipStream_t st);
 hipError_t launch_merkle4_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings,
                                const void* positions, unsigned depth, void* roots, size_t n, hipStream_t st);
 

@@ -488,11 +488,13 @@ __global__ void __launch_bounds__(P252_BLOCK) k_crypt_coop(const int32_t* __rest
     }
 }
 
-// ---- finalize_truncated post-processing (hash.rs:164-183) on device-resident digests:
-// canonical value (Montgomery form dropped) & (2^250 - 1), written as the raw limbs that
-// JubJubScalar::from_raw receives.  redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256 = the canonical value. ----
-__global__ void __launch_bounds__(P252_BLOCK) k_truncate250(const Scalar32* __restrict__ in,
-                                                            Scalar32* __restrict__ out, size_t n) {
+// ---- canonical-value outputs on device-resident scalars.  MASK250: finalize_truncated's post-processing (hash.rs:164-183):
+// canonical value (Montgomery form dropped) & (2^250 - 1), written as the raw limbs that JubJubScalar::from_raw receives.
+// Without the mask: BlsScalar::to_bytes (the 32 little-endian bytes of the canonical value; the reference uses the pair
+// to_bytes / from_bytes at src/hades/round_constants.rs:66-67 and from_hex_str at src/hades.rs:131).
+// redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256 = the canonical value. ----
+template <bool MASK250>
+__global__ void __launch_bounds__(P252_BLOCK) k_to_canonical(const Scalar32* in, Scalar32* out, size_t n) {  // (in place allowed)
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (idx >= n) return;
     const E29 x = load_scalar(in + idx);
@@ -503,9 +505,32 @@ __global__ void __launch_bounds__(P252_BLOCK) k_truncate250(const Scalar32* __re
     const E29 canon = redc(t);
     uint32_t w[8];
     to_mont4(canon, w);
-    w[7] &= 0x03ffffffu;  // TRUNCATION_MASK: keep the low 250 bits
+    if (MASK250) w[7] &= 0x03ffffffu;  // TRUNCATION_MASK: keep the low 250 bits
     *reinterpret_cast<uint4*>(out + idx) = make_uint4(w[0], w[1], w[2], w[3]);
     *(reinterpret_cast<uint4*>(out + idx) + 1) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---- BlsScalar::from_bytes on n device-resident 32-byte records: little-endian canonical value v -> the Montgomery
+// limbs of v * 2^256 mod p.  ok[i] = 1 iff v < p (from_bytes fails otherwise; the limbs written are those of v mod p).
+// One generic product by r2 = 2^517 mod p (balanced digits, kernel argument): v * 2^517 / 2^261 = v * 2^256. ----
+__global__ void __launch_bounds__(P252_BLOCK) k_from_canonical(const Scalar32* in, Scalar32* out, uint8_t* __restrict__ ok,
+                                                               size_t n, Digits9 r2) {  // (in place allowed)
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const uint4 lo = *reinterpret_cast<const uint4*>(in + idx);
+    const uint4 hi = *(reinterpret_cast<const uint4*>(in + idx) + 1);
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (ok) {
+        const uint32_t PW[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+        uint32_t borrow = 0;  // v - p borrows  <=>  v < p
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t d = (uint64_t)w[k] - PW[k] - borrow;
+            borrow = (uint32_t)(d >> 63);
+        }
+        ok[idx] = (uint8_t)borrow;
+    }
+    store_scalar(out + idx, mul_c(from_mont4(w), r2.d));
 }
 
 // ---- batched Merkle opening: recompute the root from a leaf and its sibling path (arity 4).
@@ -661,8 +686,22 @@ hipError_t launch_crypt(bool decrypt, const int32_t* tab, const TagArg& tag, con
 
 hipError_t launch_truncate250(const void* in, void* out, size_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_truncate250, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, static_cast<const Scalar32*>(in),
+    hipLaunchKernelGGL(k_to_canonical<true>, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, static_cast<const Scalar32*>(in),
                        static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_to_canonical(const void* in, void* out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_to_canonical<false>, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, static_cast<const Scalar32*>(in),
+                       static_cast<Scalar32*>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_from_canonical(const void* in, void* out, void* ok, size_t n, const Digits9& r2, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_from_canonical, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, static_cast<const Scalar32*>(in),
+                       static_cast<Scalar32*>(out), static_cast<uint8_t*>(ok), n, r2);
     return hipGetLastError();
 }
 

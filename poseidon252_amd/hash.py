@@ -227,6 +227,17 @@ class Context:
         assert d_scalars.is_cuda and d_out.is_cuda and self._nbytes(d_scalars) >= n * 32 and self._nbytes(d_out) >= n * 32
         self._check(_lib.lib().p252_truncate250_device(self._h, d_scalars.data_ptr(), d_out.data_ptr(), n, self._stream()))
 
+    # ---- the canonical byte format (BlsScalar::to_bytes / from_bytes) on device-resident arrays ----
+    def to_bytes_device(self, d_scalars, d_bytes, n):
+        assert d_scalars.is_cuda and d_bytes.is_cuda and self._nbytes(d_scalars) >= n * 32 and self._nbytes(d_bytes) >= n * 32
+        self._check(_lib.lib().p252_to_bytes_device(self._h, d_scalars.data_ptr(), d_bytes.data_ptr(), n, self._stream()))
+
+    def from_bytes_device(self, d_bytes, d_scalars, n, d_ok=None):
+        assert d_scalars.is_cuda and d_bytes.is_cuda and self._nbytes(d_scalars) >= n * 32 and self._nbytes(d_bytes) >= n * 32
+        assert d_ok is None or (d_ok.is_cuda and self._nbytes(d_ok) >= n)
+        self._check(_lib.lib().p252_from_bytes_device(self._h, d_bytes.data_ptr(), d_scalars.data_ptr(),
+                                                      d_ok.data_ptr() if d_ok is not None else None, n, self._stream()))
+
     def merkle4_path_batch(self, tag, leaves, siblings, positions):
         """leaves (n,4) u64; siblings (n,depth,3,4) u64; positions (n,depth) u8 in 0..3 -> roots (n,4)"""
         tag = _as_scalars(tag).reshape(4)
@@ -315,6 +326,30 @@ def truncate250(scalars):
     if rc:
         _raise(rc)
     return out
+
+
+def to_bytes(scalars):
+    """`BlsScalar::to_bytes` for an array of scalars: (n,4) u64 Montgomery limbs -> (n,32) u8, the little-endian bytes of the
+    canonical values (host-side; `Context.to_bytes_device` for device-resident arrays)"""
+    s = _as_scalars(scalars).reshape(-1, 4)
+    out = np.empty((s.shape[0], 32), dtype=np.uint8)
+    rc = _lib.lib().p252_to_bytes(s.ctypes.data_as(_u64p), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), s.shape[0])
+    if rc:
+        _raise(rc)
+    return out
+
+
+def from_bytes(data):
+    """`BlsScalar::from_bytes` for n records of 32 little-endian bytes -> ((n,4) u64 Montgomery limbs, ok (n,) bool);
+    ok[i] False = the value is not below p (from_bytes fails there; the limbs are those of the value mod p)"""
+    b = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32)
+    out = np.empty((b.shape[0], 4), dtype=np.uint64)
+    ok = np.zeros(b.shape[0], dtype=np.uint8)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    rc = _lib.lib().p252_from_bytes(b.ctypes.data_as(u8p), out.ctypes.data_as(_u64p), ok.ctypes.data_as(u8p), b.shape[0])
+    if rc:
+        _raise(rc)
+    return out, ok.astype(bool)
 
 
 class Hash:

@@ -36,6 +36,17 @@ int main(void) {
     CHECK(p252_tag(P252_DOMAIN_MERKLE4, lens2, 2, 1, tag2) == P252_OK && memcmp(tag, tag2, 32) == 0); /* chunks aggregate */
     CHECK(p252_merkle4_levels_len(16) == 5 && p252_merkle2_levels_len(8) == 7 && p252_tables_size() > 0);
     CHECK(p252_encryption_tag(P252_CRYPT_STREAM, 42, tag2) == P252_OK && p252_encryption_tag(7, 42, tag2) == P252_ERR_INVALID_ARGUMENT);
+    {   /* the canonical byte format (host side): 1 <-> bytes 01 00 .. 00; all-ones is not below the modulus */
+        uint8_t one_bytes[32] = {1}, ff[32], okf[2] = {9, 9}, back[32];
+        uint64_t s2[8];
+        memset(ff, 0xff, 32);
+        uint8_t two[64];
+        memcpy(two, one_bytes, 32);
+        memcpy(two + 32, ff, 32);
+        CHECK(p252_from_bytes(two, s2, okf, 2) == P252_OK && okf[0] == 1 && okf[1] == 0);
+        CHECK(s2[0] == 0x00000001fffffffeULL && s2[3] == 0x1824b159acc5056fULL); /* R = the Montgomery form of 1 */
+        CHECK(p252_to_bytes(s2, back, 1) == P252_OK && memcmp(back, one_bytes, 32) == 0);
+    }
 
     p252_ctx* ctx = NULL;
     int rc = p252_create(0, &ctx);
