@@ -304,4 +304,19 @@ inline std::vector<BlsScalar> decrypt(const std::vector<BlsScalar>& cipher, cons
     return m;
 }
 
+// ---- the canonical byte format: BlsScalar::to_bytes / from_bytes (src/hades/round_constants.rs:66-67) ----
+using ScalarBytes = std::array<std::uint8_t, 32>;  // little-endian bytes of the canonical value
+inline std::vector<ScalarBytes> to_bytes(const std::vector<BlsScalar>& scalars) {
+    std::vector<ScalarBytes> out(scalars.size());
+    if (!scalars.empty()) detail::check(p252_to_bytes(scalars[0].data(), out[0].data(), scalars.size()), nullptr, "to_bytes");
+    return out;
+}
+// ok[i] == 0 where the value is not below the modulus (BlsScalar::from_bytes returns an error there)
+inline std::vector<BlsScalar> from_bytes(const std::vector<ScalarBytes>& bytes, std::vector<std::uint8_t>& ok) {
+    std::vector<BlsScalar> out(bytes.size());
+    ok.assign(bytes.size(), 0);
+    if (!bytes.empty()) detail::check(p252_from_bytes(bytes[0].data(), out[0].data(), ok.data(), bytes.size()), nullptr, "from_bytes");
+    return out;
+}
+
 }  // namespace dusk_poseidon_hip

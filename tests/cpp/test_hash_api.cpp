@@ -58,6 +58,17 @@ int main() {
         std::vector<BlsScalar> four(input.begin(), input.begin() + 4);
         EXPECT(Hash::digest(Domain::Merkle4, four) != Hash::digest(Domain::Other, four));
     }
+    // ---- round_constants.rs:56-71: to_bytes -> from_bytes is the identity; all-ones is not a valid encoding ----
+    {
+        auto xs = random_scalars(0xb17e, 100);
+        std::vector<std::uint8_t> ok;
+        EXPECT(from_bytes(to_bytes(xs), ok) == xs);
+        for (auto o : ok) EXPECT(o == 1);
+        ScalarBytes ff;
+        ff.fill(0xff);
+        from_bytes({ff}, ok);
+        EXPECT(ok.size() == 1 && ok[0] == 0);
+    }
     // ---- tests/hash.rs shapes against the oracle ----
     for (size_t n_in : {3, 5, 15}) {
         auto input = random_scalars(0xbeef + n_in, n_in);
