@@ -476,7 +476,10 @@ P252_HD E29 from_mont4(const uint32_t w[8]) {
 }
 
 // Canonicalise: any lazy residue with -2p < V < 3p  ->  the unique limbs in [0, p), as the
-// reference's BlsScalar holds them (bit-exact comparison happens on these).
+// reference's BlsScalar holds them (bit-exact comparison happens on these).  NSUB = conditional subtractions of p:
+// 0 < V + 2p < (NSUB + 1) p must hold — 5 in general; the streaming format conversions, whose input is a tight
+// reduction of a value below p (-p < V < p), ask for 2.
+template <int NSUB = 5>
 P252_HD void to_mont4(const E29& x, uint32_t w[8]) {
     // V + 2p > 0, then pack the non-negative value into 9 u32 words
     E29 y = x;
@@ -513,7 +516,7 @@ P252_HD void to_mont4(const E29& x, uint32_t w[8]) {
                             0x3339d808u, 0x299d7d48u, 0x73eda753u, 0u};
     // subtract p while >= p: 0 < V + 2p < 6p  ->  at most 5 conditional subtractions
 #pragma unroll
-    for (int rep = 0; rep < 5; ++rep) {
+    for (int rep = 0; rep < NSUB; ++rep) {
         uint32_t dif[9];
         uint32_t borrow = 0;
 #pragma unroll

@@ -492,7 +492,13 @@ __global__ void __launch_bounds__(P252_BLOCK) k_crypt_coop(const int32_t* __rest
 // canonical value (Montgomery form dropped) & (2^250 - 1), written as the raw limbs that JubJubScalar::from_raw receives.
 // Without the mask: BlsScalar::to_bytes (the 32 little-endian bytes of the canonical value; the reference uses the pair
 // to_bytes / from_bytes at src/hades/round_constants.rs:66-67 and from_hex_str at src/hades.rs:131).
-// redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256 = the canonical value. ----
+// redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256 = the canonical value.
+// These two are the library's only HBM-bound kernels (64 B of traffic and one field product per scalar).  Measured
+// (bench_tools/byte_format_bench.py, profiles/r02_byte_format.txt): what held them at 4.5 / 4.2 TB/s was VALU work, not the
+// access pattern — one record per lane as two 16-byte loads runs exactly as fast as fully contiguous 1-KB wave
+// instructions with a DPP pair swap, and non-temporal hints change nothing; canonicalising with the 2 conditional
+// subtractions a tight reduction of a sub-modulus value needs instead of the general 5 gives 5.5 / 4.7 TB/s
+// (HBM achievable: ~6.3). ----
 template <bool MASK250>
 __global__ void __launch_bounds__(P252_BLOCK) k_to_canonical(const Scalar32* in, Scalar32* out, size_t n) {  // (in place allowed)
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
@@ -502,9 +508,9 @@ __global__ void __launch_bounds__(P252_BLOCK) k_to_canonical(const Scalar32* in,
     A29 t;
     acc_zero(t);
     acc_mul(t, x, c32);
-    const E29 canon = redc(t);
+    const E29 canon = redc(t);  // in (V / 2^256 - p, V / 2^256] with V < 2^256: between -p and p
     uint32_t w[8];
-    to_mont4(canon, w);
+    to_mont4<2>(canon, w);
     if (MASK250) w[7] &= 0x03ffffffu;  // TRUNCATION_MASK: keep the low 250 bits
     *reinterpret_cast<uint4*>(out + idx) = make_uint4(w[0], w[1], w[2], w[3]);
     *(reinterpret_cast<uint4*>(out + idx) + 1) = make_uint4(w[4], w[5], w[6], w[7]);
@@ -530,7 +536,10 @@ __global__ void __launch_bounds__(P252_BLOCK) k_from_canonical(const Scalar32* i
         }
         ok[idx] = (uint8_t)borrow;
     }
-    store_scalar(out + idx, mul_c(from_mont4(w), r2.d));
+    uint32_t m[8];
+    to_mont4<2>(mul_c(from_mont4(w), r2.d), m);  // |v r2| / 2^261 < 2^250: the tight reduction leaves a value in (-1.1 p, 0.1 p)
+    *reinterpret_cast<uint4*>(out + idx) = make_uint4(m[0], m[1], m[2], m[3]);
+    *(reinterpret_cast<uint4*>(out + idx) + 1) = make_uint4(m[4], m[5], m[6], m[7]);
 }
 
 // ---- batched Merkle opening: recompute the root from a leaf and its sibling path (arity 4).
