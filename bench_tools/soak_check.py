@@ -10,6 +10,10 @@ import numpy as np
 import oracle
 import poseidon252_amd as P
 
+if "--long" in sys.argv:  # (torch must initialise HIP before the library's staging threads exist: initialised later it finds no device)
+    import torch
+    torch.cuda.init()
+
 ctx = P.Context(0)
 t0 = time.time()
 st = oracle.fill_random(77, 5 * (1 << 18)).reshape(-1, 5, 4)
@@ -38,3 +42,89 @@ while time.time() - t0 < 25:
     assert np.array_equal(ctx.hash_batch(mtag, x, 4, 1), oracle.hash_batch(mtag, x, 4, 1, threads=8)), n
     checked += n
 print("%d Merkle4 digests in batches of 1 .. 70,000 bit-exact" % checked)
+
+# --long [minutes]: a randomized differential run over EVERY entry point (both kernel families: batch sizes straddle the
+# 8,192 / 16,384 switches), each call compared with the oracle limb for limb
+if "--long" in sys.argv:
+    from poseidon252_amd import encryption as E
+    minutes = float(sys.argv[sys.argv.index("--long") + 1]) if len(sys.argv) > sys.argv.index("--long") + 1 else 5.0
+    counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0}
+    P_ = oracle.P
+    t0 = time.time()
+    it = 0
+    while time.time() - t0 < 60 * minutes:
+        it += 1
+        seed = int(rng.integers(1, 1 << 30))
+        kind = it % 8
+        n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 8193)), int(rng.integers(8193, 20000))]))
+        if kind == 0:
+            n = min(n, 12000)
+            st = oracle.fill_random(seed, 5 * n).reshape(n, 5, 4)
+            assert np.array_equal(ctx.permute_batch(st), oracle.permute_batch(st)), ("permute", n, seed)
+            counts["permute"] += n
+        elif kind == 1:
+            in_len, out_len = int(rng.integers(1, 50)), int(rng.integers(1, 10))
+            n = min(n, 40000 // in_len + 1)
+            tag = oracle.fill_random(seed + 1, 1).reshape(4)
+            msg = oracle.fill_random(seed, n * in_len).reshape(n, in_len, 4)
+            assert np.array_equal(ctx.hash_batch(tag, msg, in_len, out_len), oracle.hash_batch(tag, msg, in_len, out_len, threads=8)), ("sponge", n, in_len, out_len, seed)
+            counts["sponge"] += n
+        elif kind == 2:
+            x = oracle.fill_random(seed, 4 * n).reshape(n, 4, 4)
+            assert np.array_equal(ctx.hash_batch(mtag, x, 4, 1), oracle.hash_batch(mtag, x, 4, 1, threads=8)), ("digest", n, seed)
+            tag2 = oracle.tag(1, [2], 1)
+            assert np.array_equal(ctx.hash_batch(tag2, np.ascontiguousarray(x[:, :2]), 2, 1), oracle.hash_batch(tag2, np.ascontiguousarray(x[:, :2]), 2, 1, threads=8))
+            counts["digest"] += 2 * n
+        elif kind == 3:
+            leaves = int(rng.choice([n, 4 ** int(rng.integers(1, 9)), 4 ** int(rng.integers(1, 8)) + int(rng.integers(1, 50))]))
+            lv = oracle.fill_random(seed, leaves)
+            root, levels = ctx.merkle4_tree(mtag, lv, want_levels=True)
+            o_root, o_levels, _ = oracle.merkle4_tree(mtag, lv, want_levels=True)
+            assert np.array_equal(root, o_root) and np.array_equal(levels, o_levels), ("tree", leaves, seed)
+            counts["tree leaves"] += leaves
+        elif kind == 4:
+            depth = int(rng.integers(0, 14))
+            n = min(n, 9000, 30000 // max(depth, 1) + 1)  # (the oracle re-hashes n * depth nodes on one core)
+            leaves = oracle.fill_random(seed, n)
+            sib = oracle.fill_random(seed + 1, n * depth * 3).reshape(n, depth, 3, 4) if depth else np.zeros((n, 0, 3, 4), dtype=np.uint64)
+            pos = rng.integers(0, 4, size=(n, depth), dtype=np.uint8)
+            assert np.array_equal(ctx.merkle4_path_batch(mtag, leaves, sib, pos), oracle.merkle4_path_batch(mtag, leaves, sib, pos)), ("openings", n, depth, seed)
+            counts["openings"] += n
+        elif kind == 5:
+            length = int(rng.choice([1, 2, 3, 4, 5, 8, 21, 42]))
+            n = min(n, 12000 // length + 1)
+            variant = int(rng.integers(0, 2))
+            msg = oracle.fill_random(seed, n * length).reshape(n, length, 4)
+            sec = oracle.fill_random(seed + 1, 2 * n).reshape(n, 2, 4)
+            non = oracle.fill_random(seed + 2, n)
+            c = E.encrypt_batch(msg, sec, non, ctx=ctx, variant=variant)
+            assert np.array_equal(c, oracle.encrypt_batch(E.encryption_tag(length, variant), msg, sec, non, variant=variant)), ("encrypt", n, length, variant, seed)
+            back, ok = E.decrypt_batch(c, sec, non, ctx=ctx, variant=variant)
+            assert ok.all() and np.array_equal(back, msg), ("decrypt", n, length, variant, seed)
+            counts["encrypt+decrypt"] += n
+        elif kind == 6:
+            x = oracle.fill_random(seed, n)
+            import torch
+            d = torch.from_numpy(x.view(np.int64)).cuda()
+            o = torch.empty_like(d)
+            ctx.truncate250_device(d, o, n)
+            torch.cuda.synchronize()
+            assert np.array_equal(o.cpu().numpy().view(np.uint64), P.truncate250(x)), ("truncate", n, seed)
+            counts["truncate"] += n
+        else:
+            import torch
+            raw = np.frombuffer(np.random.default_rng(seed).bytes(32 * n), dtype=np.uint8).reshape(n, 32)
+            d_b = torch.from_numpy(raw.copy()).cuda()
+            d_s = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+            d_ok = torch.empty(n, dtype=torch.uint8, device="cuda")
+            ctx.from_bytes_device(d_b, d_s, n, d_ok)
+            d_back = torch.empty_like(d_b)
+            ctx.to_bytes_device(d_s, d_back, n)
+            torch.cuda.synchronize()
+            h_s, h_ok = P.from_bytes(raw)
+            assert np.array_equal(d_s.cpu().numpy().view(np.uint64), h_s) and np.array_equal(d_ok.cpu().numpy().astype(bool), h_ok), ("from_bytes", n, seed)
+            vals = [int.from_bytes(r.tobytes(), "little") % P_ for r in raw[:64]]
+            assert [int.from_bytes(r.tobytes(), "little") for r in d_back.cpu().numpy()[:64]] == vals, ("to_bytes", n, seed)
+            assert np.array_equal(d_back.cpu().numpy(), P.to_bytes(h_s))
+            counts["bytes"] += n
+    print("long soak, %.1f minutes, %d calls, every result equal to the oracle's: %s" % ((time.time() - t0) / 60, it, ", ".join("%s %d" % kv for kv in counts.items())))

@@ -43,6 +43,34 @@ class ExtensionMissing(RuntimeError):
     pass
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own copy of the HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7 —
+    the same SONAME as /opt/rocm/lib's, which libposeidon252_hip.so links to), and the first copy of a SONAME loaded into a
+    process serves everyone.  Loaded after `import torch`, this library runs on torch's copy: what every test and bench
+    does.  Loaded BEFORE torch it would pull in the system copy, and a later `import torch` would then run on a runtime it
+    was not built against (observed: "RuntimeError: No HIP GPUs are available").  So when torch is installed but not yet
+    imported, load its runtime first — the order of imports then no longer matters.  P252_SYSTEM_HIP_RUNTIME=1 opts out
+    (a process that will never use torch)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("P252_SYSTEM_HIP_RUNTIME") == "1":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return path
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -51,6 +79,7 @@ def lib():
         raise ExtensionMissing(
             "%s not found: build it with `python -m poseidon252_amd.build` "
             "(hipcc --offload-arch=gfx950).  poseidon252_amd has no CPU fallback." % LIB_PATH)
+    _preload_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     if os.environ.get("P252_LIB_PATH"):
         # developer A/B switch only: an OLDER build of the library may lack entry points added since; give those a stub

@@ -338,3 +338,29 @@ print("PAD OK")
     env = dict(os.environ, P252_TREE_PAD_LANES="16384")
     out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(HERE), env=env, capture_output=True, timeout=600)
     assert out.returncode == 0 and b"PAD OK" in out.stdout, out.stdout.decode() + out.stderr.decode()
+
+
+def test_library_loaded_before_torch_leaves_torch_usable():
+    """PyTorch-ROCm bundles its own HIP runtime under the SONAME the library links to; whichever copy is loaded first
+    serves the whole process.  Loading this library first must not leave a later `import torch` without devices
+    (poseidon252_amd/_lib.py loads torch's copy first when torch is installed)."""
+    import subprocess, sys
+    code = r'''
+import sys
+import numpy as np
+import oracle, poseidon252_amd as P
+assert "torch" not in sys.modules
+ctx = P.Context(0)
+x = oracle.fill_random(1, 4 * 100).reshape(100, 4, 4)
+tag = P.merkle4_tag()
+a = ctx.hash_batch(tag, x, 4, 1)
+import torch
+assert torch.cuda.is_available() and torch.cuda.device_count() >= 1
+d = torch.from_numpy(x.view(np.int64)).cuda()
+b = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx).digest(d)
+torch.cuda.synchronize()
+assert np.array_equal(b.cpu().numpy().view(np.uint64).reshape(-1), a.reshape(-1))
+print("ORDER OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(HERE), capture_output=True, timeout=600)
+    assert out.returncode == 0 and b"ORDER OK" in out.stdout, out.stdout.decode() + out.stderr.decode()[-3000:]
