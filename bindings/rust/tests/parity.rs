@@ -13,14 +13,16 @@ use rand::SeedableRng;
 #[test]
 fn gpu_matches_reference_hash() {
     let mut rng = StdRng::seed_from_u64(0xbeef);
-    for (domain, n_in, n_out) in [
-        (Domain::Merkle4, 4, 1), (Domain::Merkle2, 2, 1), (Domain::Other, 3, 1), (Domain::Other, 5, 1),
-        (Domain::Other, 15, 1), (Domain::Other, 3, 3), (Domain::Other, 5, 2), (Domain::Other, 4, 7), (Domain::Other, 42, 5),
+    // batches of <= 8,192 items run the library's lane-group kernels, larger ones the one-lane kernels: both families are hit
+    for (domain, n_in, n_out, items) in [
+        (Domain::Merkle4, 4, 1, 1000), (Domain::Merkle2, 2, 1, 1000), (Domain::Other, 3, 1, 1000), (Domain::Other, 5, 1, 1000),
+        (Domain::Other, 15, 1, 1000), (Domain::Other, 3, 3, 1000), (Domain::Other, 5, 2, 1000), (Domain::Other, 4, 7, 1000),
+        (Domain::Other, 42, 5, 1000), (Domain::Merkle4, 4, 1, 20_000), (Domain::Merkle2, 2, 1, 12_000), (Domain::Other, 5, 2, 9_000),
     ] {
         let hb = HashBatch::with_output_len(domain, n_in, n_out).unwrap();
-        let input: Vec<BlsScalar> = (0..n_in * 1000).map(|_| BlsScalar::random(&mut rng)).collect();
+        let input: Vec<BlsScalar> = (0..n_in * items).map(|_| BlsScalar::random(&mut rng)).collect();
         let got = hb.digest(&input);
-        for i in 0..1000 {
+        for i in 0..items {
             let mut h = Hash::new(domain);
             h.output_len(n_out);
             h.update(&input[i * n_in..(i + 1) * n_in]);
@@ -29,8 +31,6 @@ fn gpu_matches_reference_hash() {
     }
 }
 
-/// `Hash::update` chunks: the README example (README.md:31-44) hashes `[..3]` then `[3..]`; the digest must equal the
-/// one-chunk hash only if dusk-safe aggregates adjacent absorbs in the tag input — printed for the record.
 #[test]
 fn byte_format_matches_the_crate() {
     // to_bytes / from_bytes of the real crate against the library's conversions (round_constants.rs:56-71 pattern)
@@ -49,6 +49,8 @@ fn byte_format_matches_the_crate() {
     assert!(BlsScalar::from_bytes(&[0xffu8; 32]).is_err());
 }
 
+/// `Hash::update` chunks: the README example (README.md:31-44) hashes `[..3]` then `[3..]`; the digest must equal the
+/// one-chunk hash only if dusk-safe aggregates adjacent absorbs in the tag input — printed for the record.
 #[test]
 fn chunked_updates_and_the_tag_input_encoding() {
     let (t1, log1) = hash_tag(Domain::Other, &[42], 1).unwrap();
