@@ -42,5 +42,6 @@ def test_lib_rs_calls_only_declared_functions_and_no_private_dusk_api():
     assert "tag_input(" not in code                        # dusk_safe::tag_input is crate-private
     assert "impl Safe<BlsScalar, 5> for TagProbe" in lib    # the tag comes from a tag-capturing Safe (src/hades.rs:63-92 pattern)
     parity = open(os.path.join(ROOT, "bindings", "rust", "tests", "parity.rs")).read()
-    for shape in ("(Domain::Other, 3, 3)", "(Domain::Other, 5, 2)", "(Domain::Other, 4, 7)", "[2usize, 21, 42]"):
-        assert shape in parity
+    for shape in ("(Domain::Other, 3, 3, ", "(Domain::Other, 5, 2, ", "(Domain::Other, 4, 7, ", "[2usize, 21, 42]",
+                  "(Domain::Merkle4, 4, 1, 20_000)"):  # the reference's tests/hash.rs shapes; a batch beyond the lane-group kernels
+        assert shape in parity, shape
