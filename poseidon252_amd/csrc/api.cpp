@@ -130,7 +130,7 @@ static int for_each_ctx(p252_ctx* const* ctxs, size_t n_ctx, F&& f) {
 
 extern "C" {
 
-const char* p252_version(void) { return "poseidon252_hip 0.3 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits)"; }
+const char* p252_version(void) { return "poseidon252_hip 0.4 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
 
 int p252_device_count(void) {
     int n = 0;
