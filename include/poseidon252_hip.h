@@ -131,6 +131,13 @@ int p252_sync(p252_ctx* ctx, void* hip_stream);
  * value & (2^250 - 1), written as the raw limbs JubJubScalar::from_raw receives.  d_out_raw may alias
  * d_scalars. */
 int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_raw, size_t n, void* hip_stream);
+/* Incremental update of a stored arity-4 tree (the poseidon-merkle consumer keeps its tree and changes leaves): writes
+ * d_new_leaves[i] to d_leaves[d_indices[i]] (k distinct uint32 positions < n_leaves) and re-hashes every ancestor, level by
+ * level, in place in d_levels (the layout p252_merkle4_tree_device fills: all levels above the leaves, bottom-up,
+ * p252_merkle4_levels_len(n_leaves) scalars).  Cost: log4(n_leaves) launches of k digests; afterwards leaves and levels equal
+ * those of a fresh build.  d_root (optional) receives the new root.  An out-of-range index is undefined behaviour. */
+int p252_merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
+                               const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* hip_stream);
 /* The canonical byte format on either side of the path: BlsScalar::to_bytes / from_bytes (dusk-bls12_381; the reference
  * round-trips its round constants through the pair, src/hades/round_constants.rs:66-67, and reads its KAT inputs with
  * from_hex_str, src/hades.rs:131).  bytes = n records of 32 little-endian bytes of the canonical value (16-byte aligned

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "p252_decrypt_batch_device",
     "p252_hash_batch_multi", "p252_hash_batch_multi_device", "p252_merkle4_tree_multi", "p252_merkle4_tree_multi_device",
     "p252_tables_size", "p252_tables_export", "p252_tables_import",
-    "p252_to_bytes_device", "p252_from_bytes_device", "p252_to_bytes", "p252_from_bytes",
+    "p252_to_bytes_device", "p252_from_bytes_device", "p252_to_bytes", "p252_from_bytes", "p252_merkle4_update_device",
     "p252_domain_separator", "p252_check_io_pattern", "p252_tag", "p252_truncate250", "p252_version",
 )
 
@@ -148,6 +148,7 @@ def lib():
     L.p252_check_io_pattern.argtypes = [ctypes.c_int, _szp, _sz, _sz]
     L.p252_tag.argtypes = [ctypes.c_int, _szp, _sz, _sz, _u64p]
     L.p252_truncate250.argtypes = [_u64p, _u64p, _sz]
+    L.p252_merkle4_update_device.argtypes = [_vp, _u64p, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp]
     L.p252_to_bytes_device.argtypes = [_vp, _vp, _vp, _sz, _vp]
     L.p252_from_bytes_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp]
     L.p252_to_bytes.argtypes = [_u64p, _u8p, _sz]

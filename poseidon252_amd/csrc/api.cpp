@@ -694,6 +694,36 @@ int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_ra
     return P252_OK;
 }
 
+// ---- incremental update of a stored arity-4 tree (the poseidon-merkle consumer changes leaves of a tree it
+// keeps): the k leaves are written into d_leaves, then every level re-hashes the (at most k) nodes above them, in place in
+// d_levels (layout of p252_merkle4_tree_device: the levels above the leaves, bottom-up); d_root (optional) gets the new root.
+int p252_merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
+                               const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n_leaves == 0 || n_leaves > 0xffffffffULL) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_update: n_leaves must be in 1 .. 2^32 - 1");
+    if (!tag || !d_leaves || (n_leaves > 1 && !d_levels)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_update: NULL buffer");
+    if (k && (!d_indices || !d_new_leaves)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_update: NULL update list");
+    if (misaligned(d_leaves) || misaligned(d_levels) || misaligned(d_new_leaves)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const TagArg t = tag_arg(tag);
+    HIP_TRY(ctx, launch_scatter_scalars(d_indices, d_new_leaves, d_leaves, k, st));
+    const char* cur = static_cast<const char*>(d_leaves);
+    size_t cur_n = n_leaves;
+    char* lv = static_cast<char*>(d_levels);
+    unsigned shift = 2;
+    while (cur_n > 1) {
+        const size_t next_n = (cur_n + 3) / 4;
+        HIP_TRY(ctx, launch_merkle4_update(ctx->d_tab, t, d_indices, shift, cur, cur_n, lv, k, st));
+        cur = lv;
+        cur_n = next_n;
+        lv += next_n * 32;
+        shift += 2;
+    }
+    if (d_root) HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
+    return P252_OK;
+}
+
 // ---- the canonical byte format of a scalar (BlsScalar::to_bytes / from_bytes; the reference round-trips its round
 // constants through the pair, src/hades/round_constants.rs:66-67, and reads its KAT inputs with from_hex_str, src/hades.rs:131)
 int p252_to_bytes_device(p252_ctx* ctx, const void* d_scalars, void* d_bytes, size_t n, void* hip_stream) {

@@ -22,6 +22,10 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 // pad_lanes > n: the n nodes are computed redundantly by pad_lanes lanes (k_merkle4_pad: narrow levels of a large tree)
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
                           void* out, size_t n, hipStream_t st, unsigned arity = 4, size_t pad_lanes = 0);
+// incremental tree update: index[k] = leaf positions (u32); one level: node = index[i] >> shift, re-hashed from `children`
+hipError_t launch_scatter_scalars(const void* index, const void* values, void* dst, size_t k, hipStream_t st);
+hipError_t launch_merkle4_update(const int32_t* tab, const TagArg& tag, const void* index, unsigned shift, const void* children,
+                                 size_t n_children, void* out, size_t k, hipStream_t st);
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
                          unsigned out_len, void* out, size_t n, hipStream_t st);
 

@@ -207,6 +207,56 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __re
     if (j == 1) store_scalar(out + idx, mine);  // the digest is element 1 of the permuted state: lane 1's
 }
 
+// ---- incremental update of a stored tree: k leaves changed; per level, update i re-hashes the node above
+// its leaf (node = leaf_index[i] >> shift) from the node's children in the level below.  Several updates under one node
+// compute it redundantly and store identical bytes.  One lane per update, or a lane group for k <= 8,192. ----
+__global__ void __launch_bounds__(P252_BLOCK) k_scatter_scalars(const uint32_t* __restrict__ index, const Scalar32* __restrict__ values,
+                                                                Scalar32* __restrict__ dst, size_t k) {
+    const size_t i = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (i >= k) return;
+    const uint4 lo = *reinterpret_cast<const uint4*>(values + i);
+    const uint4 hi = *(reinterpret_cast<const uint4*>(values + i) + 1);
+    *reinterpret_cast<uint4*>(dst + index[i]) = lo;
+    *(reinterpret_cast<uint4*>(dst + index[i]) + 1) = hi;
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_update(const int32_t* __restrict__ tab, TagArg tag,
+                                                               const uint32_t* __restrict__ index, unsigned shift,
+                                                               const Scalar32* __restrict__ children, size_t n_children,
+                                                               Scalar32* __restrict__ out, size_t k) {
+    const size_t i = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (i >= k) return;
+    const size_t node = index[i] >> shift;
+    E29 s[WIDTH];
+#pragma unroll
+    for (int d = 0; d < NL; ++d) s[0].d[d] = tag.x0[d];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[1 + c] = load_child_or_zero(children, n_children, node, 4, c);
+    hades_permute<0x02u, true>(s, tab);
+    store_scalar(out + node, s[1]);
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_update_coop(const int32_t* __restrict__ tab, TagArg tag,
+                                                                    const uint32_t* __restrict__ index, unsigned shift,
+                                                                    const Scalar32* __restrict__ children, size_t n_children,
+                                                                    Scalar32* __restrict__ out, size_t k) {
+    const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    const size_t i = lane / 8;
+    if (i >= k) return;
+    const size_t node = index[i] >> shift;
+    const int j = (int)(threadIdx.x & 7u);
+    const int el = j < WIDTH ? j : WIDTH - 1;
+    E29 mine = from_mont4(tag.w), unused;
+    {
+        const E29 child = load_child_or_zero(children, n_children, node, 4, el - 1);
+#pragma unroll
+        for (int d = 0; d < NL; ++d) mine.d[d] = el > 0 ? child.d[d] : mine.d[d];
+    }
+    unused = mine;
+    WaveComm8 cm{j, (int)(((threadIdx.x & 63u) & ~7u) * 4u)};
+    CoopLane<8> L = coop_lane<8>(tab, cm);
+    hades_permute_coop<8, false>(mine, unused, tab, cm, L);
+    if (j == 1) store_scalar(out + node, mine);
+}
+
 // ---- the other entry points for batches that cannot fill the chip (n <= 8,192): the same 8-lane groups, lane i holding
 // state element i throughout.  Bit-identical results to the one-lane kernels below (P252_COOP_MAX_NODES=0 selects those). ----
 __global__ void __launch_bounds__(P252_BLOCK) k_permute_coop(const int32_t* __restrict__ tab, const Scalar32* __restrict__ in,
@@ -647,6 +697,27 @@ hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* chi
     else
         hipLaunchKernelGGL(k_merkle4, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
                            static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_scalars(const void* index, const void* values, void* dst, size_t k, hipStream_t st) {
+    if (k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_scalars, dim3(grid_for(k)), dim3(P252_BLOCK), 0, st, static_cast<const uint32_t*>(index),
+                       static_cast<const Scalar32*>(values), static_cast<Scalar32*>(dst), k);
+    return hipGetLastError();
+}
+
+hipError_t launch_merkle4_update(const int32_t* tab, const TagArg& tag, const void* index, unsigned shift, const void* children,
+                                 size_t n_children, void* out, size_t k, hipStream_t st) {
+    if (k == 0) return hipSuccess;
+    if (coop8(k))
+        hipLaunchKernelGGL(k_merkle4_update_coop, dim3(grid_for(k * 8)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const uint32_t*>(index), shift, static_cast<const Scalar32*>(children), n_children,
+                           static_cast<Scalar32*>(out), k);
+    else
+        hipLaunchKernelGGL(k_merkle4_update, dim3(grid_for(k)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const uint32_t*>(index), shift, static_cast<const Scalar32*>(children), n_children,
+                           static_cast<Scalar32*>(out), k);
     return hipGetLastError();
 }
 

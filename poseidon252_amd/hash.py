@@ -227,6 +227,20 @@ class Context:
         assert d_scalars.is_cuda and d_out.is_cuda and self._nbytes(d_scalars) >= n * 32 and self._nbytes(d_out) >= n * 32
         self._check(_lib.lib().p252_truncate250_device(self._h, d_scalars.data_ptr(), d_out.data_ptr(), n, self._stream()))
 
+    def merkle4_update_device(self, tag, d_leaves, n_leaves, d_levels, d_indices, d_new_leaves, k, d_root=None):
+        """incremental update of a stored tree: d_leaves[d_indices[i]] = d_new_leaves[i] (k distinct positions, int32/uint32
+        tensor) and every ancestor in d_levels (the layout merkle4_tree_device fills) re-hashed; d_root gets the new root"""
+        tag = _as_scalars(tag).reshape(4)
+        assert d_leaves.is_cuda and self._nbytes(d_leaves) >= n_leaves * 32
+        assert n_leaves == 1 or (d_levels.is_cuda and self._nbytes(d_levels) >= _lib.lib().p252_merkle4_levels_len(n_leaves) * 32)
+        if k:
+            assert d_indices.is_cuda and d_indices.element_size() == 4 and d_indices.numel() >= k
+            assert d_new_leaves.is_cuda and self._nbytes(d_new_leaves) >= k * 32
+        self._check(_lib.lib().p252_merkle4_update_device(
+            self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), n_leaves, d_levels.data_ptr() if d_levels is not None else None,
+            d_indices.data_ptr() if k else None, d_new_leaves.data_ptr() if k else None, k,
+            d_root.data_ptr() if d_root is not None else None, self._stream()))
+
     # ---- the canonical byte format (BlsScalar::to_bytes / from_bytes) on device-resident arrays ----
     def to_bytes_device(self, d_scalars, d_bytes, n):
         assert d_scalars.is_cuda and d_bytes.is_cuda and self._nbytes(d_scalars) >= n * 32 and self._nbytes(d_bytes) >= n * 32

@@ -139,3 +139,36 @@ def test_merkle_path_random_and_device_api(gpu_ctx, oracle_mod):
             assert np.array_equal(d_r.cpu().numpy().view(np.uint64), exp)
     with pytest.raises(ValueError):
         gpu_ctx.merkle4_path_batch(tag, leaves[:1], np.zeros((1, 1, 3, 4), dtype=np.uint64), np.array([[7]], dtype=np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_leaves,k", [(1, 1), (5, 2), (4 ** 6, 1), (4 ** 6, 300), (4 ** 6 + 3, 4 ** 6 + 3), (70001, 9000), (70001, 7), (4 ** 8, 20000)])
+def test_incremental_tree_update(gpu_ctx, oracle_mod, n_leaves, k):
+    """p252_merkle4_update_device: k leaves of a stored tree change; leaves, every level and the root must
+    equal a fresh build over the updated leaves (oracle).  k <= 8,192 runs the lane-group kernel, more the one-lane one;
+    updates cluster under shared parents and touch the ragged last node."""
+    import torch
+    tag = oracle_mod.tag(0, [4], 1)
+    leaves = oracle_mod.fill_random(3 * n_leaves + k, n_leaves)
+    total = oracle_mod.levels_total(n_leaves)
+    d_leaves = torch.from_numpy(leaves.view(np.int64).copy()).cuda()
+    d_levels = torch.zeros((max(total, 1), 4), dtype=torch.int64, device="cuda")
+    d_root = torch.zeros(4, dtype=torch.int64, device="cuda")
+    gpu_ctx.merkle4_tree_device(tag, d_leaves, n_leaves, d_root, d_levels)
+    rng = np.random.default_rng(n_leaves + k)
+    idx = rng.permutation(n_leaves)[:k].astype(np.int64)
+    if k >= 4 and n_leaves >= 8:
+        idx[:4] = [n_leaves - 1, n_leaves - 2, 0, 1]  # the ragged last node and one shared parent
+        idx = np.unique(idx)
+        k = idx.shape[0]
+    new = oracle_mod.fill_random(99 + k, k)
+    d_idx = torch.from_numpy(idx.astype(np.int32)).cuda()
+    d_new = torch.from_numpy(new.view(np.int64).copy()).cuda()
+    gpu_ctx.merkle4_update_device(tag, d_leaves, n_leaves, d_levels, d_idx, d_new, k, d_root)
+    torch.cuda.synchronize()
+    updated = leaves.copy()
+    updated[idx] = new
+    o_root, o_levels, _ = oracle_mod.merkle4_tree(tag, updated, want_levels=True)
+    assert np.array_equal(d_leaves.cpu().numpy().view(np.uint64), updated)
+    assert np.array_equal(d_levels.cpu().numpy().view(np.uint64)[:total], o_levels)
+    assert np.array_equal(d_root.cpu().numpy().view(np.uint64), o_root)
