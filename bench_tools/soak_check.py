@@ -48,14 +48,14 @@ print("%d Merkle4 digests in batches of 1 .. 70,000 bit-exact" % checked)
 if "--long" in sys.argv:
     from poseidon252_amd import encryption as E
     minutes = float(sys.argv[sys.argv.index("--long") + 1]) if len(sys.argv) > sys.argv.index("--long") + 1 else 5.0
-    counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0}
+    counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0, "tree updates": 0}
     P_ = oracle.P
     t0 = time.time()
     it = 0
     while time.time() - t0 < 60 * minutes:
         it += 1
         seed = int(rng.integers(1, 1 << 30))
-        kind = it % 8
+        kind = it % 9
         n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 8193)), int(rng.integers(8193, 20000))]))
         if kind == 0:
             n = min(n, 12000)
@@ -111,6 +111,26 @@ if "--long" in sys.argv:
             torch.cuda.synchronize()
             assert np.array_equal(o.cpu().numpy().view(np.uint64), P.truncate250(x)), ("truncate", n, seed)
             counts["truncate"] += n
+        elif kind == 8:
+            import torch
+            leaves_n = int(rng.choice([int(rng.integers(1, 5000)), 4 ** int(rng.integers(1, 9)), int(rng.integers(5000, 80000))]))
+            k = int(min(leaves_n, rng.choice([1, int(rng.integers(1, 200)), int(rng.integers(200, 12000))])))
+            lv = oracle.fill_random(seed, leaves_n)
+            total = oracle.levels_total(leaves_n)
+            d_lv = torch.from_numpy(lv.view(np.int64).copy()).cuda()
+            d_levels = torch.zeros((max(total, 1), 4), dtype=torch.int64, device="cuda")
+            d_root = torch.zeros(4, dtype=torch.int64, device="cuda")
+            ctx.merkle4_tree_device(mtag, d_lv, leaves_n, d_root, d_levels)
+            idx = rng.permutation(leaves_n)[:k]
+            new = oracle.fill_random(seed + 1, k)
+            ctx.merkle4_update_device(mtag, d_lv, leaves_n, d_levels, torch.from_numpy(idx.astype(np.int32)).cuda(),
+                                      torch.from_numpy(new.view(np.int64).copy()).cuda(), k, d_root)
+            torch.cuda.synchronize()
+            upd = lv.copy()
+            upd[idx] = new
+            o_root, o_levels, _ = oracle.merkle4_tree(mtag, upd, want_levels=True)
+            assert np.array_equal(d_levels.cpu().numpy().view(np.uint64)[:total], o_levels) and np.array_equal(d_root.cpu().numpy().view(np.uint64), o_root), ("update", leaves_n, k, seed)
+            counts["tree updates"] += k
         else:
             import torch
             raw = np.frombuffer(np.random.default_rng(seed).bytes(32 * n), dtype=np.uint8).reshape(n, 32)
