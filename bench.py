@@ -5,21 +5,35 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-the default workload is BASELINE.json configs[1] — 2^20 independent Hash::digest(Domain::Merkle4,
-4 random BlsScalar) per GPU, one Hades permutation each, one kernel launch (k_merkle4).  Scaling is
-weak: every rank hashes its own 2^20-digest batch, no data-path collective (digests are independent);
-rank 0 broadcasts the constant table over RCCL once, before the timed region.  Setup also issues 24 untimed
-launches of the step (`setup.wake_up_launches`) so that an idle GPU's clocks are at steady state whatever W is;
-then W untimed warm-up steps, then exactly K timed steps between barriers + synchronisation, MAX over ranks.
-Other workloads: --workload tree | sponge42 | openings | encrypt (BASELINE configs[2], [3]).
+the PRIMARY workload (the top-level keys of the JSON line) is BASELINE.json configs[1] — 2^20 independent
+Hash::digest(Domain::Merkle4, 4 random BlsScalar) per GPU, one Hades permutation each, one kernel launch
+(k_merkle4).  Scaling is weak: every rank hashes its own 2^20-digest batch, no data-path collective (digests
+are independent); rank 0 broadcasts the constant table over RCCL once, before the timed region.  Per workload:
+untimed wake-up launches of the step (so that an idle GPU's clocks are at steady state whatever W is), W untimed
+warm-up steps, then exactly K timed steps between barriers + synchronisation, MAX over ranks.
+
+The same command then times the other BASELINE configs as SECONDARY workloads, reported under "secondary" with the
+same discipline (their own wake-up, warm-up, barriers, max over ranks) — so that every config is measured by whoever
+runs this one command:
+  secondary.tree      BASELINE configs[2]: 2^24-leaf arity-4 Merkle tree per GPU, all levels; at N > 1 every rank
+                      reduces its subtree, the N roots (32 B each) are all-gathered — the path's only exchange step —
+                      and the top levels are hashed on every rank: at N = 8 that IS configs[4] (2^27 leaves)
+  secondary.sponge42  BASELINE configs[3]: Domain::Other sponge, 2^20 messages x 42 scalars -> 5 outputs per GPU
+(--no-secondary skips them; --workload X makes X the primary and runs no secondary; --log2n scales the primary.)
+
+The shader clock is MEASURED inside the run: a one-wave probe kernel (p252_clock_probe_device: s_memtime
+against the 100 MHz s_memrealtime) runs on a second stream beside extra untimed steps immediately before and after
+each timed region — the clock under this very load — and every roofline fraction is given at the nominal 2.4 GHz
+AND at the measured clock.
 
 Prints ONE JSON line (rank 0) with `roofline` (VALU int32-MAC bound — DESIGN.md §3; HBM figures are
 included, the path is not HBM- or MFMA-bound) and, at N=1, `cpu_baseline` (the C oracle, kind "port",
 timed on the host cores on a bounded sample).  oracle/ is touched ONLY inside that cpu_baseline leg,
-where it is timed and, as a by-product, checks a sample of the GPU output just measured; every run
-(any N) additionally performs an oracle-free GPU self-consistency check.
+where it is timed and, as a by-product, checks a sample of the GPU output of every workload just measured; every
+run (any N) additionally performs an oracle-free GPU self-consistency check per workload.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,16 +51,26 @@ BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 1
                   "encrypt": (5 * 32 + 3 * 32) / 2.0}             # 2 message + 2 secret + 1 nonce scalars in, 3 cipher scalars out
 KERNEL_OF = {"merkle4_digests": "k_merkle4", "tree": "k_merkle4", "sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}
 # VALU issue peak of the chip (the binding roofline): a wave64 v_mad_i64_i32 occupies its SIMD for 4
-# cycles, so 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s = 39.3 T lane-MACs/s.  The clock is the one
-# GRBM_GUI_ACTIVE / duration shows during this very kernel (profiles/r02_pmc_k_merkle4.txt: 2.40 GHz).  For reference,
-# the best a pure dependent-free multiply-add stream was MEASURED to sustain after clock ramp is lower
-# (profiles/r02_valu_rates_gfx950.txt: 531 G/s at 4 waves per SIMD) — reported beside it, never used as the peak,
+# cycles, so 1024 SIMDs x clock / 4 wave-instructions/s; x 64 lanes = lane-MACs/s.  At the nominal 2.4 GHz that is
+# 614.4 G wave-instructions/s = 39.3 T lane-MACs/s — `peak`.  The clock the chip actually holds under this load is lower
+# and differs from box to box (2.26-2.37 GHz seen): it is measured in the run and the fractions are given at it as well.
+# For reference, the best a pure dependent-free multiply-add stream was MEASURED to sustain after clock ramp
+# (profiles/r02_valu_rates_gfx950.txt: 531 G/s at 4 waves per SIMD) is reported beside it, never used as the peak,
 # because a peak the kernel's own instruction mix can exceed is not a peak.
 SIMDS, NOMINAL_CLOCK_HZ = 1024, 2.4e9
 PEAK_WAVE_INST_4CYCLE_PER_S = SIMDS * NOMINAL_CLOCK_HZ / 4.0
 PEAK_INT32_MAC_PER_S = PEAK_WAVE_INST_4CYCLE_PER_S * 64
 MEASURED_MAD_STREAM_WAVE_INST_PER_S = 531.2e9
 PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# the kernel sources a counter pass or an ISA count belongs to (profiles/*.json carry the digest of these files)
+KERNEL_SOURCES = ("kernels.hip", "fr29.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h")
+
+
+def kernel_sources_sha256():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "poseidon252_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def _latest(pattern):
@@ -75,8 +99,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # the clocks need ~10 launches (25 ms) to ramp from idle
-    ap.add_argument("--workload", default="merkle4_digests", choices=["merkle4_digests", "tree", "sponge42", "openings", "encrypt"])
-    ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step (default: 20; tree: 24 leaves)")
+    ap.add_argument("--workload", default=None, choices=["merkle4_digests", "tree", "sponge42", "openings", "encrypt"],
+                    help="primary workload (default merkle4_digests = BASELINE configs[1], followed by the secondary workloads)")
+    ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step of the primary (default: 20; tree: 24 leaves)")
+    ap.add_argument("--no-secondary", action="store_true", help="do not time the secondary workloads (tree, sponge42)")
+    ap.add_argument("--secondary-log2n", type=int, default=None, help="(tests) scale the secondary workloads: 2^k sponge messages, 2^(k+4) tree leaves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -85,7 +112,9 @@ def parse():
 def pmc_profile(kernel):
     """the committed rocprofv3 --pmc summary of `kernel` from the latest round (tools/run_pmc.sh + tools/pmc_summary.py:
     counters collected in separate passes; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled on gfx950 as
-    MI355X_MICROARCH.md §HBM prescribes) — bench.py cannot run the profiler on itself"""
+    MI355X_MICROARCH.md §HBM prescribes) — bench.py cannot run the profiler on itself.  A summary records the digest of
+    the kernel sources it was collected from; one that belongs to other sources is reported as stale, never silently used
+    (tests/test_profiles_fresh.py keeps the default line's files fresh)."""
     path = _latest("r*_pmc_%s.json" % kernel)
     if not path:
         return None
@@ -94,14 +123,17 @@ def pmc_profile(kernel):
     except (OSError, ValueError):
         return None
     d["source"] = os.path.relpath(path, ROOT)
+    d["stale"] = d.get("kernel_sources_sha256") != kernel_sources_sha256()
     return d
 
 
 def pmc_traffic(kernel, workload, units_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed --pmc passes, scaled to this launch size"""
-    d = pmc_profile(kernel)
-    if not d or "hbm_bytes_per_launch" not in d or workload == "tree":  # (a tree is 12 launches of different sizes)
+    """HBM bytes per step from the committed --pmc passes of the kernel(s) the workload runs, scaled to this size"""
+    d = pmc_profile(kernel if workload != "tree" else "tree")
+    if not d or "hbm_bytes_per_launch" not in d:
         return None
+    if d["stale"]:
+        return {"bytes": None, "stale_source": d["source"], "note": "the committed counter pass belongs to other kernel sources"}
     scale = units_per_launch / d["units_per_launch"]
     return {"bytes": d["hbm_bytes_per_launch"] * scale, "algorithmic_bytes": BYTES_PER_PERM[workload] * units_per_launch,
             "ratio": d["hbm_bytes_per_launch"] * scale / (BYTES_PER_PERM[workload] * units_per_launch), "source": d["source"]}
@@ -111,7 +143,7 @@ def pmc_valu(kernel):
     """what the counters say about the same kernel: VALU instructions per wave (must equal the ISA-derived count) and
     the clock during the kernel (GRBM_GUI_ACTIVE / 8 XCDs / duration)"""
     d = pmc_profile(kernel)
-    if not d or "valu_insts_per_wave" not in d:
+    if not d or "valu_insts_per_wave" not in d or d["stale"]:
         return None
     out = {"valu_insts_per_wave": d["valu_insts_per_wave"], "source": d["source"]}
     if d.get("clock_ghz"):
@@ -119,32 +151,36 @@ def pmc_valu(kernel):
     return out
 
 
-def usable_cpus():
-    """threads worth starting: min(affinity mask, cgroup CPU quota) — the GPU box reports 256 logical CPUs
-    but a container quota may allow far fewer"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def cpu_quota():
+    """CPUs the cgroup grants (None = unlimited)"""
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
             if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                quota = int(txt[0])
-                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if quota > 0:
-                    n = min(n, max(1, quota // period))
-            break
+                return None if txt[0] == "max" else int(txt[0]) / int(txt[1])
+            quota = int(txt[0])
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return quota / period if quota > 0 else None
         except (OSError, ValueError, IndexError):
             continue
+    return None
+
+
+def usable_cpus():
+    """threads worth starting: min(affinity mask, cgroup CPU quota) — the GPU box reports 256 logical CPUs
+    but a container quota may allow far fewer"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = cpu_quota()
+    if q:
+        n = min(n, max(1, int(q)))
     return max(1, n)
 
 
-def cpu_baseline(tag, gpu_sample=None):
+def cpu_baseline(tag, gpu_samples=()):
     """The oracle (C restatement of the reference CPU path, reference schedule: 2000 mults/perm) on the
-    host cores.  Bounded sample: 2^14 digests on 1 thread, then 2^14 per thread on all threads.
-    gpu_sample = (kind, inputs, in_len, out_len, gpu_output): inputs of the run just timed with the GPU's
-    answers — recomputed here on the CPU and compared (reported as parity_sample_ok)."""
+    host cores.  Bounded sample: 2^12 digests on 1 thread, then 2^14 per thread on all threads.
+    gpu_samples = [(name, kind, tag, inputs, in_len, out_len, gpu_output)]: inputs of the runs just timed with the GPU's
+    answers — recomputed here on the CPU and compared (reported as parity_sample_ok, per workload in parity_samples)."""
     import oracle
     try:  # rebuild for this host's ISA when a compiler is present (mulx/adx); fall back to the shipped build
         import subprocess
@@ -194,20 +230,23 @@ def cpu_baseline(tag, gpu_sample=None):
                 break
     except OSError:
         pass
-    parity = None
-    if gpu_sample is not None:
-        kind, inp, in_len, out_len, got = gpu_sample
+    parity = {}
+    for name, kind, stag, inp, in_len, out_len, got in gpu_samples:
         if kind == "tree":
-            exp = oracle.merkle4_tree(tag, inp)[0]
+            exp = oracle.merkle4_tree(stag, inp)[0]
         elif kind == "encrypt":
-            exp = oracle.encrypt_batch(tag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
+            exp = oracle.encrypt_batch(stag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
         elif kind == "paths":
-            exp = oracle.merkle4_path_batch(tag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
+            exp = oracle.merkle4_path_batch(stag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
         else:
-            exp = oracle.hash_batch(tag, inp, in_len, out_len)
-        parity = bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(exp).reshape(-1)))
-    return {"parity_sample_ok": parity,
-            "value": nall / best, "unit": "permutations/s", "cores": threads, "kind": "port",
+            exp = oracle.hash_batch(stag, inp, in_len, out_len)
+        parity[name] = bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(exp).reshape(-1)))
+    quota = cpu_quota()
+    return {"parity_sample_ok": (all(parity.values()) if parity else None), "parity_samples": parity,
+            "value": nall / best, "unit": "permutations/s",
+            # `cores` (the contract's key) = the THREADS the multi-threaded figure used — the count that ran fastest; the
+            # box grants fewer CPUs than that through its cgroup quota (cpu_quota) and shows many more (cpus_visible)
+            "cores": threads, "threads": threads, "cpu_quota": quota, "cpus_visible": os.cpu_count(), "kind": "port",
             "sample": "Hash::digest(Merkle4, 4 scalars): %d digests per sample on %d threads, 1 thread: %d digests per sample; "
                       "warm-up + 10 samples each, median reported (min in *_min)" % (nall, threads, n1),
             "value_min_time": nall / float(np.min(allt)), "value_1core": n1 / t1, "value_1core_min_time": n1 / float(np.min(one)),
@@ -235,6 +274,303 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required for RCCL across processes on this driver
     sys.exit(subprocess.call(cmd, env=env))
+
+
+class Env:
+    """what every workload needs: the context, the device, the process group"""
+
+    def __init__(self, torch, dist, ctx, dev, coll_dev, rank, world):
+        self.torch, self.dist, self.ctx, self.dev, self.coll_dev, self.rank, self.world = torch, dist, ctx, dev, coll_dev, rank, world
+        self.side = torch.cuda.Stream(device=dev)  # the clock probe's stream
+
+    def barrier(self):
+        if self.dist.is_initialized():
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if not self.dist.is_initialized():
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+class Workload:
+    """one BASELINE config as synthetic device-resident input + a step; see make_workload"""
+    pass
+
+
+def make_workload(E, wl, log2n):
+    import poseidon252_amd as P
+    from poseidon252_amd import synth
+    torch, dist, ctx, dev, rank, world = E.torch, E.dist, E.ctx, E.dev, E.rank, E.world
+    W = Workload()
+    W.key, W.depth = wl, 12
+    if wl == "merkle4_digests":
+        log2n = log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        in_scalars, W.perms_per_step = 4 * n, n
+        W.name = "2^%d independent Merkle4 digests per GPU (BASELINE configs[1])" % log2n
+        W.wake = 24
+    elif wl == "tree":
+        log2n = log2n or 24
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        in_scalars, W.perms_per_step = n, P.levels_len(n)
+        W.name = "2^%d-leaf arity-4 Merkle tree per GPU, all levels (BASELINE configs[2])" % log2n
+        W.wake = 6
+    elif wl == "encrypt":
+        log2n = log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)  # (only for the context; the tag below is the encryption tag)
+        in_scalars, W.perms_per_step = 5 * n, 2 * n
+        W.name = "2^%d encryptions of 2-scalar messages per GPU (2 permutations each, SURVEY §8 f4; recipe unpinned)" % log2n
+        W.wake = 12
+    elif wl == "openings":
+        log2n = log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        in_scalars, W.perms_per_step = n * (1 + 3 * W.depth), W.depth * n
+        W.name = "2^%d Merkle4 openings of depth %d per GPU (branch re-hash, SURVEY §8 f3)" % (log2n, W.depth)
+        W.wake = 4
+    else:
+        log2n = log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Other, 42, output_len=5, ctx=ctx)
+        in_scalars, W.perms_per_step = 42 * n, 12 * n
+        W.name = "Domain::Other sponge, 2^%d messages x 42 scalars -> 5 outputs per GPU (BASELINE configs[3])" % log2n
+        W.wake = 4
+    W.n, W.log2n = n, log2n
+    tag = hb.tag
+    if wl == "encrypt":
+        from poseidon252_amd import encryption as Enc
+        tag = Enc.encryption_tag(2)
+    W.tag = tag
+    # synthetic input generated ON the device by SURVEY §8(d)'s generator (splitmix64 stream, rejection-sampled below p:
+    # uniform field elements; poseidon252_amd/synth.py, byte-identical to the oracle's fill_random).  Rank 0's
+    # configs[1] batch (seed 0xc10d) is exactly the one tests/test_gpu_fullsize.py verifies digest by digest.
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC10D + rank)
+    d_in = synth.splitmix_scalars(0xC10D + rank, in_scalars, dev)
+    W.d_in = d_in
+    depth = W.depth
+    if wl == "merkle4_digests":
+        d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        W.step = lambda: ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
+    elif wl == "tree":
+        d_out = torch.empty(4, dtype=torch.int64, device=dev)
+        if world == 1:
+            W.step = lambda: ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
+        else:
+            # BASELINE configs[4] structure: every rank reduces its complete subtree, the W roots (32 B each)
+            # are all-gathered (the path's only exchange step) and the top levels are hashed on every rank
+            coll_dev = E.coll_dev
+            d_roots = torch.empty(world * 4, dtype=torch.int64, device=coll_dev)  # flat: gloo and nccl both accept it
+            d_top = torch.empty(4, dtype=torch.int64, device=dev)
+            W.d_top = d_top
+
+            def step():
+                ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
+                dist.all_gather_into_tensor(d_roots, d_out if coll_dev == dev else d_out.cpu())
+                roots_dev = d_roots if coll_dev == dev else d_roots.to(dev)
+                ctx.merkle4_tree_device(tag, roots_dev.contiguous(), world, d_top, None)
+            W.step = step
+            W.perms_per_step += P.levels_len(world)
+            W.name += " + all-gather of %d subtree roots and top levels" % world
+            if world == 8 and log2n == 24:
+                W.name += " = 2^27-leaf tree sharded across 8 GPUs (BASELINE configs[4])"
+        W.step()  # allocate the context-owned level scratch outside the timed region
+    elif wl == "encrypt":
+        d_out = torch.empty((n, 3, 4), dtype=torch.int64, device=dev)
+        d_msgs, d_secrets, d_nonces = d_in[:2 * n], d_in[2 * n:4 * n], d_in[4 * n:]
+        W.step = lambda: Enc.encrypt_batch_device(d_msgs, d_secrets, d_nonces, 2, d_out, n, ctx=ctx, tag=tag)
+    elif wl == "openings":
+        d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        d_leaves, d_sibs = d_in[:n], d_in[n:]
+        d_pos = torch.randint(0, 4, (n, depth), dtype=torch.uint8, device=dev, generator=g)
+        W.step = lambda: ctx.merkle4_path_batch_device(tag, d_leaves, d_sibs, d_pos, depth, d_out, n)
+    else:
+        d_out = torch.empty((n, 5, 4), dtype=torch.int64, device=dev)
+        W.step = lambda: ctx.hash_batch_device(tag, d_in, 42, 5, d_out, n)
+    W.d_out = d_out
+
+    def self_check():
+        """correctness of what was just timed, WITHOUT the oracle (every rank, every N): a slice of the batch is
+        hashed again on its own and must reproduce the same digests (shard consistency + determinism)"""
+        if wl == "merkle4_digests":
+            lo, cnt = n // 3, min(n - n // 3, 4096)
+            again = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
+            ctx.hash_batch_device(tag, d_in[lo * 4:(lo + cnt) * 4], 4, 1, again, cnt)
+            torch.cuda.synchronize()
+            return bool(torch.equal(again, d_out[lo:lo + cnt]))
+        if wl == "tree":
+            # subtree composition: the tree over the 4 quarter-tree roots is the tree's root
+            quarters = torch.stack([P.merkle4_tree(d_in[i * (n // 4):(i + 1) * (n // 4)], tag=tag, ctx=ctx) for i in range(4)])
+            top = P.merkle4_tree(quarters.contiguous(), tag=tag, ctx=ctx)
+            ref = torch.empty(4, dtype=torch.int64, device=dev)
+            ctx.merkle4_tree_device(tag, d_in, n, ref, None)
+            torch.cuda.synchronize()
+            return bool(torch.equal(top, ref) and torch.equal(ref, d_out))
+        if wl == "encrypt":
+            # decrypting what was just produced gives the messages back, with every authentication flag set
+            back = torch.empty((n, 2, 4), dtype=torch.int64, device=dev)
+            ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+            Enc.decrypt_batch_device(d_out, d_secrets, d_nonces, 2, back, ok, n, ctx=ctx, tag=tag)
+            torch.cuda.synchronize()
+            return bool(torch.equal(back.view(-1, 4), d_msgs) and bool(ok.all()))
+        if wl == "openings":
+            lo, cnt = n // 3, min(n - n // 3, 4096)
+            again = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
+            ctx.merkle4_path_batch_device(tag, d_leaves[lo:lo + cnt], d_sibs[lo * 3 * depth:(lo + cnt) * 3 * depth], d_pos[lo:lo + cnt].contiguous(),
+                                          depth, again, cnt)
+            torch.cuda.synchronize()
+            return bool(torch.equal(again, d_out[lo:lo + cnt]))
+        lo, cnt = n // 3, min(n - n // 3, 1024)
+        again = torch.empty((cnt, 5, 4), dtype=torch.int64, device=dev)
+        ctx.hash_batch_device(tag, d_in[lo * 42:(lo + cnt) * 42], 42, 5, again, cnt)
+        torch.cuda.synchronize()
+        return bool(torch.equal(again, d_out[lo:lo + cnt]))
+    W.self_check = self_check
+
+    def oracle_sample():
+        """(kind, tag, inputs, in_len, out_len, gpu_output) of a strided sample of what was just timed — handed to the
+        cpu_baseline leg, the only place the oracle runs"""
+        if wl == "tree":  # a 4^6-leaf subtree at the front of the same leaves, built by the same entry point
+            sub = min(n, 1 << 12)
+            got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
+            return ("tree", tag, d_in[:sub].cpu().numpy().view(np.uint64), None, None, got)
+        if wl == "merkle4_digests":
+            idx = torch.arange(0, n, max(1, n // 512), device=dev)
+            return ("hash", tag, d_in.view(n, 4, 4)[idx].cpu().numpy().view(np.uint64), 4, 1, d_out[idx].cpu().numpy().view(np.uint64).reshape(-1, 1, 4))
+        idx = torch.arange(0, n, max(1, n // 128), device=dev)
+        if wl == "encrypt":
+            return ("encrypt", tag, tuple(t.cpu().numpy().view(np.uint64) for t in (d_msgs.view(n, 2, 4)[idx], d_secrets.view(n, 2, 4)[idx], d_nonces[idx])),
+                    None, None, d_out[idx].cpu().numpy().view(np.uint64))
+        if wl == "openings":
+            return ("paths", tag, (d_leaves[idx].cpu().numpy().view(np.uint64), d_sibs.view(n, depth, 3, 4)[idx].cpu().numpy().view(np.uint64),
+                                   d_pos[idx].cpu().numpy()), None, None, d_out[idx].cpu().numpy().view(np.uint64))
+        return ("hash", tag, d_in.view(n, 42, 4)[idx].cpu().numpy().view(np.uint64), 42, 5, d_out[idx].cpu().numpy().view(np.uint64))
+    W.oracle_sample = oracle_sample
+    return W
+
+
+def probe_under_load(E, W, step_ms, n_steps=4):
+    """the shader clock while `n_steps` untimed steps of the workload run: the one-wave probe (p252_clock_probe_device) is
+    launched on a second stream after the first of them and sleeps for about 1.5 steps"""
+    torch = E.torch
+    spin_us = int(min(60000.0, max(400.0, 1500.0 * step_ms)))
+    W.step()
+    t = E.ctx.clock_probe(spin_us=spin_us, stream=E.side)
+    for _ in range(n_steps - 1):
+        W.step()
+    torch.cuda.synchronize()
+    r = E.ctx.clock_probe_result(t)
+    return r if 0.3 < r["shader_ghz"] < 4.0 else None
+
+
+def run_timed(E, W, steps, warmup):
+    """wake-up launches, `warmup` untimed steps, exactly `steps` timed steps between barriers; HIP events per step on the
+    launch stream; the clock probe beside extra untimed steps immediately before and after the timed region"""
+    torch = E.torch
+    # Device wake-up (setup, reported in the JSON line): an idle MI355X needs ~25 ms of activity before its clocks
+    # reach the steady state a running service sees (profiles/r01_bench_kernel_trace_v9.txt: the first ten launches are up
+    # to 25 % slower).  A fixed count per workload (not a time): every rank must issue the same collectives at N > 1.
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i in range(W.wake):
+        if i == W.wake - 1:
+            e0.record()
+        W.step()
+    e1.record()
+    torch.cuda.synchronize()
+    step_ms_est = e0.elapsed_time(e1)
+    for _ in range(warmup):
+        W.step()
+    clk_before = probe_under_load(E, W, step_ms_est)
+    E.barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        W.step()  # launched on torch's current stream; the events below are recorded on that same stream
+        evs[i + 1].record()
+    E.barrier()
+    elapsed = time.perf_counter() - t0
+    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    clk_after = probe_under_load(E, W, step_ms_est)
+    elapsed = E.max_over_ranks(elapsed)
+    return elapsed, launch_ms, clk_before, clk_after
+
+
+def sysfs_sclk_mhz(torch, local_rank):
+    """the driver's own reading of this GPU's shader clock (hwmon freq1_input), where the box exposes it — a cross-check
+    of the probe, sampled outside the timed region"""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        import glob
+        paths = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*/freq1_input" % bdf)
+        return int(open(paths[0]).read()) / 1e6 if paths else None
+    except Exception:
+        return None
+
+
+def roofline_of(W, launch_ms, clk_before, clk_after, sclk_sysfs=None):
+    wl, n = W.key, W.n
+    k_ms = float(np.mean(launch_ms))
+    per_gpu_rate = W.perms_per_step / (k_ms * 1e-3)
+    achieved_mac = per_gpu_rate * MACS_PER_PERM_REFERENCE
+    hbm_gbps = per_gpu_rate * BYTES_PER_PERM[wl] / 1e9
+    kern = KERNEL_OF[wl]
+    lanes_per_perm, isa_key, pmc_key = 1, None, None
+    coop_max = int(os.environ.get("P252_COOP_MAX_NODES", "16384"))
+    items = n  # independent states per launch (digests, messages, openings)
+    if wl == "merkle4_digests" and 8192 < items <= min(coop_max, 16384):
+        kern, lanes_per_perm, isa_key, pmc_key = "k_merkle4_coop<4>", 4, "k_merkle4_coop<4>", "k_merkle4_coop4"
+    elif wl in ("merkle4_digests", "sponge42", "openings", "encrypt") and items <= min(coop_max, 8192):
+        # batches this small run the lane-group kernels: eight lanes per state (csrc/coop29.hpp); the permutation body is
+        # the one of k_merkle4_coop<8>, whose ISA counts and counter passes stand for all of them
+        kern = {"merkle4_digests": "k_merkle4_coop<8>", "sponge42": "k_sponge_coop", "openings": "k_merkle4_path_coop", "encrypt": "k_crypt_coop"}[wl]
+        lanes_per_perm, isa_key, pmc_key = 8, "k_merkle4_coop<8>", "k_merkle4_coop8"
+    clocks = [c["shader_ghz"] for c in (clk_before, clk_after) if c]
+    ghz = float(np.mean(clocks)) if clocks else None
+    clock = {"ghz_measured": ghz, "before": clk_before, "after": clk_after, "nominal_ghz": NOMINAL_CLOCK_HZ / 1e9,
+             "sysfs_sclk_mhz": sclk_sysfs,
+             "method": "one-wave probe kernel (s_memtime / s_memrealtime at 100 MHz) on a second stream beside untimed steps of this "
+                       "workload, immediately before and after the timed region"}
+    peak_meas = SIMDS * ghz * 1e9 / 4.0 * 64 if ghz else None
+    isa = isa_counts(isa_key or kern)
+    executed = issue = None
+    if isa:
+        mac_rate = per_gpu_rate * lanes_per_perm * isa["v_mad_i64_i32"]
+        executed = {"macs_per_perm": isa["v_mad_i64_i32"] * lanes_per_perm, "achieved": mac_rate / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12,
+                    "frac": mac_rate / PEAK_INT32_MAC_PER_S, "unit": "TMAC/s", "source": isa["source"],
+                    "peak_at_measured_clock": peak_meas / 1e12 if peak_meas else None,
+                    "frac_at_measured_clock": mac_rate / peak_meas if peak_meas else None,
+                    "frac_of_measured_mad_stream": mac_rate / (MEASURED_MAD_STREAM_WAVE_INST_PER_S * 64),
+                    "note": "the fraction of the hardware: multiply-adds actually issued (counted in the ISA) / (1024 SIMDs x clock / 4 cycles x 64 lanes), "
+                            "at the nominal 2.4 GHz (frac) and at the clock measured in this run (frac_at_measured_clock)"}
+        # every VALU instruction priced at its issue cost (4 cycles for multiply-adds, 64-bit adds / shifts and VOP3
+        # 3-operand forms, 2 for plain 32-bit ops — profiles/r02_valu_rates_gfx950.txt): share of all SIMD cycles
+        cyc = per_gpu_rate * lanes_per_perm / 64.0 * isa["valu_issue_cycles"]
+        issue = {"valu_insts_per_perm": isa["valu_total"], "lanes_per_perm": lanes_per_perm, "issue_cycles_per_perm": isa["valu_issue_cycles"],
+                 "frac": cyc / (SIMDS * NOMINAL_CLOCK_HZ), "frac_at_measured_clock": cyc / (SIMDS * ghz * 1e9) if ghz else None,
+                 "pmc": pmc_valu(pmc_key or kern),
+                 "note": "SIMD cycles spent issuing VALU work under the 4-/2-cycle model / all SIMD cycles (at 2.4 GHz; at the measured clock)"}
+    return {
+        "bound": "valu-int32-mac", "kernel": kern,
+        "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
+        "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
+        "note": "SURVEY §8d figure: 256,000 MACs per permutation (reference schedule) x permutations per launch / mean launch time "
+                "(HIP events on the launch stream) against the VALU issue peak.  The kernel runs an algebraically equivalent schedule with "
+                "4x fewer multiply-adds, so this exceeds 1 and says nothing about the hardware; `executed.frac` does.",
+        "executed": executed, "valu_issue": issue, "clock": clock,
+        "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
+        "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
+                "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
+        "traffic": pmc_traffic(pmc_key or kern, wl, W.perms_per_step),
+    }
 
 
 def main():
@@ -283,250 +619,91 @@ def main():
     from poseidon252_amd import distributed as D
     ctx = P.Context(local_rank)
     tables_identical = D.broadcast_tables(ctx, device=coll_dev)  # RCCL broadcast of the constants (no-op at N=1)
+    E = Env(torch, dist, ctx, dev, coll_dev, rank, world)
 
-    wl = args.workload
-    if wl == "merkle4_digests":
-        log2n = args.log2n or 20
-        n = 1 << log2n
-        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
-        in_scalars, perms_per_step = 4 * n, n
-        name = "2^%d independent Merkle4 digests per GPU (BASELINE configs[1])" % log2n
-    elif wl == "tree":
-        log2n = args.log2n or 24
-        n = 1 << log2n
-        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
-        in_scalars, perms_per_step = n, P.levels_len(n)
-        name = "2^%d-leaf arity-4 Merkle tree per GPU, all levels (BASELINE configs[2])" % log2n
-    elif wl == "encrypt":
-        log2n = args.log2n or 20
-        n = 1 << log2n
-        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)  # (only for the context; the tag below is the encryption tag)
-        in_scalars, perms_per_step = 5 * n, 2 * n
-        name = "2^%d encryptions of 2-scalar messages per GPU (2 permutations each, SURVEY §8 f4; recipe unpinned)" % log2n
-    elif wl == "openings":
-        log2n = args.log2n or 20
-        n = 1 << log2n
-        depth = 12
-        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
-        in_scalars, perms_per_step = n * (1 + 3 * depth), depth * n
-        name = "2^%d Merkle4 openings of depth %d per GPU (branch re-hash, SURVEY §8 f3)" % (log2n, depth)
-    else:
-        log2n = args.log2n or 20
-        n = 1 << log2n
-        hb = P.HashBatch(P.Domain.Other, 42, output_len=5, ctx=ctx)
-        in_scalars, perms_per_step = 42 * n, 12 * n
-        name = "Domain::Other sponge, 2^%d messages x 42 scalars -> 5 outputs per GPU (BASELINE configs[3])" % log2n
-    tag = hb.tag
-    if wl == "encrypt":
-        from poseidon252_amd import encryption as E
-        tag = E.encryption_tag(2)
+    primary_key = args.workload or "merkle4_digests"
+    secondary_keys = [] if (args.workload or args.no_secondary) else ["tree", "sponge42"]
+    sclk0 = sysfs_sclk_mhz(torch, local_rank)
 
-    # synthetic input generated ON the device by SURVEY §8(d)'s generator (splitmix64 stream, rejection-sampled below p:
-    # uniform field elements; poseidon252_amd/synth.py, byte-identical to the oracle's fill_random).  Rank 0's
-    # configs[1] batch (seed 0xc10d) is exactly the one tests/test_gpu_fullsize.py verifies digest by digest.
-    from poseidon252_amd import synth
-    g = torch.Generator(device=dev)
-    g.manual_seed(0xC10D + rank)
-    d_in = synth.splitmix_scalars(0xC10D + rank, in_scalars, dev)
-    if wl == "merkle4_digests":
-        d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
-        step = lambda: ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
-    elif wl == "tree":
-        d_out = torch.empty(4, dtype=torch.int64, device=dev)
-        if world == 1:
-            step = lambda: ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
-        else:
-            # BASELINE configs[4] structure: every rank reduces its complete subtree, the W roots (32 B each)
-            # are all-gathered (the path's only exchange step) and the top levels are hashed on every rank
-            d_roots = torch.empty(world * 4, dtype=torch.int64, device=coll_dev)  # flat: gloo and nccl both accept it
-            d_top = torch.empty(4, dtype=torch.int64, device=dev)
+    def measure(key, log2n, steps, warmup):
+        W = make_workload(E, key, log2n)
+        elapsed, launch_ms, cb, ca = run_timed(E, W, steps, warmup)
+        ok = None
+        if not args.no_check:
+            ok = W.self_check()
+            if not ok:
+                print("SELF-CONSISTENCY FAILURE on rank %d (%s)" % (rank, key), file=sys.stderr)
+                sys.exit(3)
+        sample = W.oracle_sample() if (rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_check) else None
+        return W, elapsed, launch_ms, cb, ca, ok, sample
 
-            def step():
-                ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
-                dist.all_gather_into_tensor(d_roots, d_out if coll_dev == dev else d_out.cpu())
-                roots_dev = d_roots if coll_dev == dev else d_roots.to(dev)
-                ctx.merkle4_tree_device(tag, roots_dev.contiguous(), world, d_top, None)
-            perms_per_step += P.levels_len(world)
-            name += " + all-gather of %d subtree roots and top levels" % world
-            if world == 8 and log2n == 24:
-                name += " = 2^27-leaf tree sharded across 8 GPUs (BASELINE configs[4])"
-        step()  # allocate the context-owned level scratch outside the timed region
-    elif wl == "encrypt":
-        d_out = torch.empty((n, 3, 4), dtype=torch.int64, device=dev)
-        d_msgs, d_secrets, d_nonces = d_in[:2 * n], d_in[2 * n:4 * n], d_in[4 * n:]
-        step = lambda: E.encrypt_batch_device(d_msgs, d_secrets, d_nonces, 2, d_out, n, ctx=ctx, tag=tag)
-    elif wl == "openings":
-        d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
-        d_leaves, d_sibs = d_in[:n], d_in[n:]
-        d_pos = torch.randint(0, 4, (n, depth), dtype=torch.uint8, device=dev, generator=g)
-        step = lambda: ctx.merkle4_path_batch_device(tag, d_leaves, d_sibs, d_pos, depth, d_out, n)
-    else:
-        d_out = torch.empty((n, 5, 4), dtype=torch.int64, device=dev)
-        step = lambda: ctx.hash_batch_device(tag, d_in, 42, 5, d_out, n)
-
-    def barrier():
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Device wake-up (setup, reported in the JSON line): an idle MI355X needs ~25 ms of activity before its clocks
-    # reach the steady state a running service sees (profiles/r01_bench_kernel_trace_v9.txt: the first ten launches are up
-    # to 25 % slower).  Done here so that the measurement does not depend on how many warm-up steps the caller asks
-    # for; the W warm-up steps and the K timed steps below are untouched.
-    WAKE_UP_LAUNCHES = 24  # a fixed count (not a time): every rank must issue the same collectives at N > 1
-    for _ in range(WAKE_UP_LAUNCHES):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    evs[0].record()
-    for i in range(args.steps):
-        step()  # launched on torch's current stream; the events below are recorded on that same stream
-        evs[i + 1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
-    if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # correctness of what was just timed, WITHOUT the oracle (every rank, every N): a slice of the batch is
-    # hashed again on its own and must reproduce the same digests (shard consistency + determinism)
-    self_ok = None
-    if not args.no_check:
-        if wl == "merkle4_digests":
-            lo, cnt = n // 3, min(n - n // 3, 4096)
-            again = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
-            ctx.hash_batch_device(tag, d_in[lo * 4:(lo + cnt) * 4], 4, 1, again, cnt)
-            torch.cuda.synchronize()
-            self_ok = bool(torch.equal(again, d_out[lo:lo + cnt]))
-        elif wl == "tree":
-            # subtree composition: the tree over the 4 quarter-tree roots is the tree's root
-            quarters = torch.stack([P.merkle4_tree(d_in[i * (n // 4):(i + 1) * (n // 4)], tag=tag, ctx=ctx) for i in range(4)])
-            top = P.merkle4_tree(quarters.contiguous(), tag=tag, ctx=ctx)
-            ref = torch.empty(4, dtype=torch.int64, device=dev)
-            ctx.merkle4_tree_device(tag, d_in, n, ref, None)
-            torch.cuda.synchronize()
-            self_ok = bool(torch.equal(top, ref))
-        elif wl == "encrypt":
-            # decrypting what was just produced gives the messages back, with every authentication flag set
-            back = torch.empty((n, 2, 4), dtype=torch.int64, device=dev)
-            ok = torch.zeros(n, dtype=torch.uint8, device=dev)
-            E.decrypt_batch_device(d_out, d_secrets, d_nonces, 2, back, ok, n, ctx=ctx, tag=tag)
-            torch.cuda.synchronize()
-            self_ok = bool(torch.equal(back.view(-1, 4), d_msgs) and bool(ok.all()))
-        elif wl == "openings":
-            lo, cnt = n // 3, min(n - n // 3, 4096)
-            again = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
-            ctx.merkle4_path_batch_device(tag, d_leaves[lo:lo + cnt], d_sibs[lo * 3 * depth:(lo + cnt) * 3 * depth], d_pos[lo:lo + cnt].contiguous(),
-                                          depth, again, cnt)
-            torch.cuda.synchronize()
-            self_ok = bool(torch.equal(again, d_out[lo:lo + cnt]))
-        else:
-            lo, cnt = n // 3, min(n - n // 3, 1024)
-            again = torch.empty((cnt, 5, 4), dtype=torch.int64, device=dev)
-            ctx.hash_batch_device(tag, d_in[lo * 42:(lo + cnt) * 42], 42, 5, again, cnt)
-            torch.cuda.synchronize()
-            self_ok = bool(torch.equal(again, d_out[lo:lo + cnt]))
-        if not self_ok:
-            print("SELF-CONSISTENCY FAILURE on rank %d" % rank, file=sys.stderr)
-            sys.exit(3)
-
+    W, elapsed, launch_ms, cb, ca, self_ok, sample = measure(primary_key, args.log2n, args.steps, args.warmup)
+    samples = [(primary_key,) + sample] if sample else []
+    line = None
     if rank == 0:
-        total_perms = perms_per_step * args.steps * world
-        value = total_perms / elapsed
-        k_ms = float(np.mean(launch_ms))
-        per_gpu_rate = perms_per_step / (k_ms * 1e-3)
-        achieved_mac = per_gpu_rate * MACS_PER_PERM_REFERENCE
-        hbm_gbps = per_gpu_rate * BYTES_PER_PERM[wl] / 1e9
-        kern = KERNEL_OF[wl]
-        lanes_per_perm, isa_key, pmc_key = 1, None, None
-        coop_max = int(os.environ.get("P252_COOP_MAX_NODES", "16384"))
-        items = n  # independent states per launch (digests, messages, openings)
-        if wl == "merkle4_digests" and 8192 < items <= min(coop_max, 16384):
-            kern, lanes_per_perm, isa_key, pmc_key = "k_merkle4_coop<4>", 4, "k_merkle4_coop<4>", "k_merkle4_coop4"
-        elif wl in ("merkle4_digests", "sponge42", "openings", "encrypt") and items <= min(coop_max, 8192):
-            # batches this small run the lane-group kernels: eight lanes per state (csrc/coop29.hpp); the permutation body is
-            # the one of k_merkle4_coop<8>, whose ISA counts and counter passes stand for all of them
-            kern = {"merkle4_digests": "k_merkle4_coop<8>", "sponge42": "k_sponge_coop", "openings": "k_merkle4_path_coop", "encrypt": "k_crypt_coop"}[wl]
-            lanes_per_perm, isa_key, pmc_key = 8, "k_merkle4_coop<8>", "k_merkle4_coop8"
-        isa = isa_counts(isa_key or kern)
-        executed = issue = None
-        if isa:
-            mac_rate = per_gpu_rate * lanes_per_perm * isa["v_mad_i64_i32"]
-            executed = {"macs_per_perm": isa["v_mad_i64_i32"] * lanes_per_perm, "achieved": mac_rate / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12,
-                        "frac": mac_rate / PEAK_INT32_MAC_PER_S, "unit": "TMAC/s", "source": isa["source"],
-                        "frac_of_measured_mad_stream": mac_rate / (MEASURED_MAD_STREAM_WAVE_INST_PER_S * 64),
-                        "note": "the fraction of the hardware: multiply-adds actually issued (counted in the ISA) / (1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes)"}
-            # every VALU instruction priced at its issue cost (4 cycles for multiply-adds, 64-bit adds / shifts and VOP3
-            # 3-operand forms, 2 for plain 32-bit ops — profiles/r02_valu_rates_gfx950.txt): share of all SIMD cycles
-            cyc = per_gpu_rate * lanes_per_perm / 64.0 * isa["valu_issue_cycles"]
-            issue = {"valu_insts_per_perm": isa["valu_total"], "lanes_per_perm": lanes_per_perm, "issue_cycles_per_perm": isa["valu_issue_cycles"],
-                     "frac": cyc / (SIMDS * NOMINAL_CLOCK_HZ), "pmc": pmc_valu(pmc_key or kern),
-                     "note": "SIMD cycles spent issuing VALU work under the 4-/2-cycle model / all SIMD cycles at 2.4 GHz"}
-        roofline = {
-            "bound": "valu-int32-mac", "kernel": kern,
-            "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
-            "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
-            "note": "SURVEY §8d figure: 256,000 MACs per permutation (reference schedule) x permutations per launch / mean launch time "
-                    "(HIP events on the launch stream) against the VALU issue peak.  The kernel runs an algebraically equivalent schedule with "
-                    "4x fewer multiply-adds, so this exceeds 1 and says nothing about the hardware; `executed.frac` does.",
-            "executed": executed, "valu_issue": issue,
-            "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
-            "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
-                    "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
-            "traffic": pmc_traffic(pmc_key or kern, wl, perms_per_step),
-        }
+        total_perms = W.perms_per_step * args.steps * world
+        roofline = roofline_of(W, launch_ms, cb, ca, {"idle_before_run": sclk0, "after_timed_region": sysfs_sclk_mhz(torch, local_rank)})
         line = {
             "metric": "Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact",
-            "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total_perms / elapsed, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "dtype_note": "255-bit field elements as 9 x 29-bit limbs (int32), products accumulated in signed 64-bit columns (v_mad_i64_i32)",
-            "config": {"workload": name, "units_per_gpu_per_step": perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
+            "config": {"workload": W.name, "units_per_gpu_per_step": W.perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
                        "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input": "splitmix64 seed 0xc10d + rank, uniform mod p (SURVEY §8d)",
                        "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
             "roofline": roofline,
             # the same kernel priced against the HBM roofline in the contract's shape (NOT the binding bound here)
-            "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": hbm_gbps / PEAK_HBM_GBPS, "traffic": roofline["traffic"]},
+            "roofline_hbm": {"bound": "hbm", "achieved": roofline["hbm"]["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": roofline["hbm"]["frac"], "traffic": roofline["traffic"]},
             "self_consistency_ok": self_ok,
-            "setup": {"wake_up_launches": WAKE_UP_LAUNCHES,
-                      "note": "untimed launches of the same step before the W warm-up steps: brings an idle GPU's clocks to steady state"},
+            "setup": {"wake_up_launches": W.wake,
+                      "note": "untimed launches of the same step before the W warm-up steps: brings an idle GPU's clocks to steady state; "
+                              "4 + 4 more untimed steps carry the clock probe before and after the timed region"},
         }
+    del W
+    torch.cuda.empty_cache()
+
+    # ---- secondary workloads: the other BASELINE configs, same discipline, same command ----
+    secondary = {}
+    for key in secondary_keys:
+        s_steps = max(2, min(args.steps, 20))
+        s_warm = min(args.warmup, 5)
+        s_log2n = None
+        if args.secondary_log2n is not None:
+            s_log2n = args.secondary_log2n + (4 if key == "tree" else 0)
+        W2, el2, lm2, cb2, ca2, ok2, sample2 = measure(key, s_log2n, s_steps, s_warm)
+        if sample2:
+            samples.append((key,) + sample2)
+        if rank == 0:
+            r2 = roofline_of(W2, lm2, cb2, ca2)
+            secondary[key] = {
+                "workload": W2.name, "units_per_gpu_per_step": W2.perms_per_step, "steps": s_steps, "warmup": s_warm,
+                "wake_up_launches": W2.wake, "ms_per_step": el2 / s_steps * 1e3, "value": W2.perms_per_step * s_steps * world / el2,
+                "unit": "permutations/s", "n_gpus": world,
+                "ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                "exchange": ("all-gather of %d x 32-byte subtree roots per step" % world) if (key == "tree" and world > 1) else None,
+                "roofline": r2, "self_consistency_ok": ok2, "parity_sample_ok": None,
+            }
+        del W2
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        if secondary_keys:
+            line["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             # the cpu_baseline leg is the ONLY place bench.py touches oracle/: it times the CPU restatement and,
-            # as a by-product, checks a strided sample of the GPU output just measured against it
-            sample = None
-            if not args.no_check:
-                h_in = d_in.cpu().numpy().view(np.uint64)
-                if wl == "merkle4_digests":
-                    idx = np.arange(0, n, max(1, n // 512))
-                    sample = ("hash", h_in.reshape(n, 4, 4)[idx], 4, 1, d_out.cpu().numpy().view(np.uint64)[idx].reshape(-1, 1, 4))
-                elif wl == "tree":
-                    sub = 1 << 12
-                    got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
-                    sample = ("tree", h_in[:sub], None, None, got)
-                elif wl == "encrypt":
-                    idx = np.arange(0, n, max(1, n // 128))
-                    sample = ("encrypt", (h_in[:2 * n].reshape(n, 2, 4)[idx], h_in[2 * n:4 * n].reshape(n, 2, 4)[idx], h_in[4 * n:][idx]), None, None,
-                              d_out.cpu().numpy().view(np.uint64)[idx])
-                elif wl == "openings":
-                    idx = np.arange(0, n, max(1, n // 128))
-                    sample = ("paths", (h_in[:n][idx], h_in[n:].reshape(n, depth, 3, 4)[idx], d_pos.cpu().numpy()[idx]), None, None,
-                              d_out.cpu().numpy().view(np.uint64)[idx])
-                else:
-                    idx = np.arange(0, n, max(1, n // 128))
-                    sample = ("hash", h_in.reshape(n, 42, 4)[idx], 42, 5, d_out.cpu().numpy().view(np.uint64).reshape(n, 5, 4)[idx])
-            line["cpu_baseline"] = cpu_baseline(tag, sample)
+            # as a by-product, checks a strided sample of the GPU output of every workload just measured against it
+            import poseidon252_amd as P2
+            line["cpu_baseline"] = cpu_baseline(P2.merkle4_tag(), samples)
+            for key, okp in line["cpu_baseline"]["parity_samples"].items():
+                if key in secondary:
+                    secondary[key]["parity_sample_ok"] = okp
             if line["cpu_baseline"].get("parity_sample_ok") is False:
-                print("PARITY FAILURE: GPU output differs from the oracle", file=sys.stderr)
+                print("PARITY FAILURE: GPU output differs from the oracle: %s" % line["cpu_baseline"]["parity_samples"], file=sys.stderr)
                 sys.exit(3)
         print(json.dumps(line))
     if dist.is_initialized():

@@ -48,6 +48,15 @@
 extern "C" {
 #endif
 
+/* Version of this interface.  Bindings compare it with p252_abi_version() of the library they loaded: a function that
+ * changes its argument list keeps its name only together with a new number here.
+ *   4  p252_encryption_tag / p252_{encrypt,decrypt}_batch[_device] take a leading `int variant`; the default construction
+ *      of every wrapper is P252_CRYPT_STREAM (version 0.2 of the library had no selector and computed P252_CRYPT_DUPLEX:
+ *      ciphertexts of messages longer than 4 scalars made then decrypt only with variant = P252_CRYPT_DUPLEX)
+ *   5  + p252_abi_version, p252_merkle4_update_checked_device, p252_clock_probe_device, p252_staging_lanes; out-of-range
+ *      indices of p252_merkle4_update_device are skipped (were undefined behaviour) */
+#define P252_ABI_VERSION 5
+
 #define P252_OK 0
 #define P252_ERR_IO_PATTERN_VIOLATION (-1) /* dusk_poseidon::Error::IOPatternViolation, src/error.rs:12-14 */
 #define P252_ERR_INVALID_IO_PATTERN (-2)   /* dusk_poseidon::Error::InvalidIOPattern,   src/error.rs:16-17 */
@@ -135,9 +144,16 @@ int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_ra
  * d_new_leaves[i] to d_leaves[d_indices[i]] (k distinct uint32 positions < n_leaves) and re-hashes every ancestor, level by
  * level, in place in d_levels (the layout p252_merkle4_tree_device fills: all levels above the leaves, bottom-up,
  * p252_merkle4_levels_len(n_leaves) scalars).  Cost: log4(n_leaves) launches of k digests; afterwards leaves and levels equal
- * those of a fresh build.  d_root (optional) receives the new root.  An out-of-range index is undefined behaviour. */
+ * those of a fresh build.  d_root (optional) receives the new root.  An index >= n_leaves is skipped (nothing is written for
+ * it).  The positions must be distinct: the same position twice with different values leaves one of them — or, the two
+ * 16-byte halves of a scalar being stored separately, a mix — in the leaf, and the levels above consistent with whatever
+ * was stored.  The _checked variant additionally counts the skipped indices: *d_n_bad (a device uint32 the caller has
+ * zeroed) is incremented once per out-of-range index. */
 int p252_merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
                                const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* hip_stream);
+int p252_merkle4_update_checked_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
+                                       const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* d_n_bad,
+                                       void* hip_stream);
 /* The canonical byte format on either side of the path: BlsScalar::to_bytes / from_bytes (dusk-bls12_381; the reference
  * round-trips its round constants through the pair, src/hades/round_constants.rs:66-67, and reads its KAT inputs with
  * from_hex_str, src/hades.rs:131).  bytes = n records of 32 little-endian bytes of the canonical value (16-byte aligned
@@ -190,7 +206,9 @@ int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
 
 /* ---- multi-device: an array of contexts, one per GPU.  Shards are contiguous and independent: no
  * inter-GPU dependence and no collective on the data path.  The calls are synchronous; inside, one host thread drives
- * each context.  A context may appear only once.  On failure the error text is on ctxs[0] (p252_last_error). ---- */
+ * each context.  A context may appear only once, and when the node has at least n_ctx devices no two contexts may be bound
+ * to the same one (P252_MULTI_ALLOW_SHARED_DEVICE=1 lifts that).  The contexts share the process's CPU budget: each uses
+ * p252_staging_lanes(n_ctx) staging lanes for pageable buffers.  On failure the error text is on ctxs[0] (p252_last_error). ---- */
 /* n digests / sponges, item i of the batch on device floor-split: device t hashes a contiguous n/n_ctx slice (sizes
  * differ by at most one); per-item results identical to p252_hash_batch. */
 int p252_hash_batch_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
@@ -233,7 +251,20 @@ int p252_truncate250(const uint64_t* scalars, uint64_t* out_raw, size_t n);
 int p252_to_bytes(const uint64_t* scalars, uint8_t* bytes, size_t n);
 int p252_from_bytes(const uint8_t* bytes, uint64_t* scalars, uint8_t* ok, size_t n);
 
+/* ---- measurement aids (bench.py; not on the hashing path) ---- */
+/* Launches ONE wave on `hip_stream` that samples the shader-clock counter (s_memtime) and the constant 100 MHz real-time
+ * counter (s_memrealtime) before and after sleeping for about spin_us microseconds, and writes
+ * d_out6[6] (uint64, device) = {memtime0, realtime0, memtime after a chain of 1,024 dependent v_add_u32, memtime1, realtime1,
+ * chain result}: (memtime1 - memtime0) / (realtime1 - realtime0) x 100 MHz = the shader clock over the interval.  On a stream
+ * of its own while hashing kernels run it measures the clock under that load. */
+int p252_clock_probe_device(p252_ctx* ctx, void* d_out6, unsigned spin_us, void* hip_stream);
+/* staging lanes (worker threads) each context uses for pageable host buffers when n_ctx contexts are driven at once by a
+ * p252_*_multi call: clamp(floor(usable CPUs / n_ctx) - 1, 1, 3); n_ctx <= 1: the single-context default (3; 2 below four
+ * CPUs).  P252_HOST_LANES overrides both. */
+int p252_staging_lanes(size_t n_ctx);
+
 /* library/version introspection */
+int p252_abi_version(void); /* P252_ABI_VERSION the library was built from */
 const char* p252_version(void);
 
 #ifdef __cplusplus

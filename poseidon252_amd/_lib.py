@@ -30,7 +30,9 @@ ABI_SYMBOLS = (
     "p252_tables_size", "p252_tables_export", "p252_tables_import",
     "p252_to_bytes_device", "p252_from_bytes_device", "p252_to_bytes", "p252_from_bytes", "p252_merkle4_update_device",
     "p252_domain_separator", "p252_check_io_pattern", "p252_tag", "p252_truncate250", "p252_version",
+    "p252_abi_version", "p252_merkle4_update_checked_device", "p252_clock_probe_device", "p252_staging_lanes",
 )
+ABI_VERSION = 5  # include/poseidon252_hip.h P252_ABI_VERSION this binding was written against
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _szp = ctypes.POINTER(ctypes.c_size_t)
@@ -154,6 +156,20 @@ def lib():
     L.p252_to_bytes.argtypes = [_u64p, _u8p, _sz]
     L.p252_from_bytes.argtypes = [_u8p, _u64p, _u8p, _sz]
     L.p252_version.restype = ctypes.c_char_p
+    L.p252_merkle4_update_checked_device.argtypes = [_vp, _u64p, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp]
+    L.p252_clock_probe_device.argtypes = [_vp, _vp, ctypes.c_uint, _vp]
+    L.p252_staging_lanes.argtypes = [_sz]
+    L.p252_abi_version.restype = ctypes.c_int
+    if not os.environ.get("P252_LIB_PATH"):
+        # argument lists changed between versions under unchanged names: never call into a library whose
+        # interface is not the one these argtypes describe
+        try:
+            have = L.p252_abi_version()
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            raise ExtensionMissing("%s implements ABI version %s, this binding needs %d: rebuild it (python -m poseidon252_amd.build)"
+                                   % (LIB_PATH, have, ABI_VERSION))
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("p252_device_count",):

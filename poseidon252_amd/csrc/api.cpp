@@ -49,6 +49,7 @@ struct p252_ctx {
         Slot slot[2];
     };
     std::vector<Lane> lanes;
+    int lane_budget = 0;  // > 0: staging lanes this call may use (set by the p252_*_multi drivers, which share the CPU quota)
     // encryption: the sponge-call program of the last (variant, message_len) used, uploaded once (k_crypt interprets it)
     uint32_t* d_prog = nullptr;
     size_t d_prog_cap = 0;
@@ -130,7 +131,9 @@ static int for_each_ctx(p252_ctx* const* ctxs, size_t n_ctx, F&& f) {
 
 extern "C" {
 
-const char* p252_version(void) { return "poseidon252_hip 0.4 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
+int p252_abi_version(void) { return P252_ABI_VERSION; }
+
+const char* p252_version(void) { return "poseidon252_hip 0.5 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
 
 int p252_device_count(void) {
     int n = 0;
@@ -330,30 +333,55 @@ struct HostSpan {  // one per-item array of a batched call: item i occupies byte
     size_t stride;
 };
 
-static int staging_lanes_wanted() {
-    static const int lanes = [] {
-        if (const char* e = std::getenv("P252_HOST_LANES")) {
-            const int v = std::atoi(e);
-            return v < 1 ? 1 : (v > 32 ? 32 : v);
-        }
-        // Three lanes x two slots keep the PCIe link busy; MORE lanes are slower on the benchmark box (16 CPUs of cgroup
-        // budget, 256 visible): 3 lanes 3.6-3.8e8 digests/s, 6 lanes 3.1-3.3e8, 12 lanes 2.0-2.2e8
-        // (profiles/r02_host_path.txt).  Two when the process may use fewer than four CPUs.
-        double cpus = (double)std::thread::hardware_concurrency();
+// CPUs this process may actually use: min(affinity mask, cgroup v2 quota).  The benchmark box shows 256 logical CPUs and
+// grants 16.
+static double cpu_budget() {
+    static const double cpus = [] {
+        double c = (double)std::thread::hardware_concurrency();
         cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = (double)CPU_COUNT(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) c = (double)CPU_COUNT(&set);
         if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
             char q[32];
             double period = 0;
             if (std::fscanf(f, "%31s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
                 const double quota = std::atof(q) / period;
-                if (quota > 0 && quota < cpus) cpus = quota;
+                if (quota > 0 && quota < c) c = quota;
             }
             std::fclose(f);
         }
-        return cpus < 4 ? 2 : 3;
+        return c < 1 ? 1.0 : c;
+    }();
+    return cpus;
+}
+
+static int staging_lanes_env() {  // P252_HOST_LANES: 0 = not set
+    static const int lanes = [] {
+        if (const char* e = std::getenv("P252_HOST_LANES")) {
+            const int v = std::atoi(e);
+            return v < 1 ? 1 : (v > 32 ? 32 : v);
+        }
+        return 0;
     }();
     return lanes;
+}
+
+// staging lanes of ONE context driven on its own
+static int staging_lanes_wanted() {
+    if (staging_lanes_env()) return staging_lanes_env();
+    // Three lanes x two slots keep the PCIe link busy; MORE lanes are slower on the benchmark box (16 CPUs of cgroup
+    // budget, 256 visible): 3 lanes 3.6-3.8e8 digests/s, 6 lanes 3.1-3.3e8, 12 lanes 2.0-2.2e8
+    // (profiles/r02_host_path.txt).  Two when the process may use fewer than four CPUs.
+    return cpu_budget() < 4 ? 2 : 3;
+}
+
+// staging lanes per context when n_ctx contexts are driven at once (p252_*_multi: one driver thread per context, each a
+// staging lane itself, plus its extra lanes): the contexts SHARE the CPU budget — 8 contexts x 3 lanes under a 16-CPU quota
+// is the 24-worker configuration the single-context sweep measured at half speed.
+static int staging_lanes_per_ctx(size_t n_ctx) {
+    if (staging_lanes_env()) return staging_lanes_env();
+    if (n_ctx <= 1) return staging_lanes_wanted();
+    int per = (int)(cpu_budget() / (double)n_ctx) - 1;
+    return per < 1 ? 1 : (per > 3 ? 3 : per);
 }
 
 // Runs `launch(d_in[], d_out[], first_item, count, stream)` over n items in chunks of `chunk`, streaming the input arrays
@@ -363,7 +391,7 @@ template <class Launch>
 static int staged_run(p252_ctx* ctx, size_t n, size_t chunk, const std::vector<HostSpan>& ins, const std::vector<HostSpan>& outs,
                       Launch&& launch) {
     const size_t n_chunks = (n + chunk - 1) / chunk;
-    const int lanes_wanted = staging_lanes_wanted();
+    const int lanes_wanted = ctx->lane_budget > 0 ? ctx->lane_budget : staging_lanes_wanted();
     const int n_lanes = (int)(n_chunks < (size_t)lanes_wanted ? n_chunks : (size_t)lanes_wanted);
     if ((int)ctx->lanes.size() < n_lanes) ctx->lanes.resize(n_lanes);
     auto layout = [&](const std::vector<HostSpan>& spans, std::vector<size_t>& offs) {  // sub-buffer offsets, total bytes
@@ -697,8 +725,8 @@ int p252_truncate250_device(p252_ctx* ctx, const void* d_scalars, void* d_out_ra
 // ---- incremental update of a stored arity-4 tree (the poseidon-merkle consumer changes leaves of a tree it
 // keeps): the k leaves are written into d_leaves, then every level re-hashes the (at most k) nodes above them, in place in
 // d_levels (layout of p252_merkle4_tree_device: the levels above the leaves, bottom-up); d_root (optional) gets the new root.
-int p252_merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
-                               const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* hip_stream) {
+static int merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
+                                 const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* d_n_bad, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (n_leaves == 0 || n_leaves > 0xffffffffULL) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_update: n_leaves must be in 1 .. 2^32 - 1");
     if (!tag || !d_leaves || (n_leaves > 1 && !d_levels)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_update: NULL buffer");
@@ -707,7 +735,7 @@ int p252_merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_lea
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     const TagArg t = tag_arg(tag);
-    HIP_TRY(ctx, launch_scatter_scalars(d_indices, d_new_leaves, d_leaves, k, st));
+    HIP_TRY(ctx, launch_scatter_scalars(d_indices, d_new_leaves, d_leaves, k, n_leaves, d_n_bad, st));
     const char* cur = static_cast<const char*>(d_leaves);
     size_t cur_n = n_leaves;
     char* lv = static_cast<char*>(d_levels);
@@ -722,6 +750,19 @@ int p252_merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_lea
     }
     if (d_root) HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
     return P252_OK;
+}
+
+int p252_merkle4_update_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
+                               const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* hip_stream) {
+    return merkle4_update_device(ctx, tag, d_leaves, n_leaves, d_levels, d_indices, d_new_leaves, k, d_root, nullptr, hip_stream);
+}
+
+int p252_merkle4_update_checked_device(p252_ctx* ctx, const uint64_t tag[4], void* d_leaves, size_t n_leaves, void* d_levels,
+                                       const void* d_indices, const void* d_new_leaves, size_t k, void* d_root, void* d_n_bad,
+                                       void* hip_stream) {
+    if (!d_n_bad) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_update_checked: d_n_bad is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_n_bad) & 3u) != 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_update_checked: d_n_bad must be 4-byte aligned");
+    return merkle4_update_device(ctx, tag, d_leaves, n_leaves, d_levels, d_indices, d_new_leaves, k, d_root, d_n_bad, hip_stream);
 }
 
 // ---- the canonical byte format of a scalar (BlsScalar::to_bytes / from_bytes; the reference round-trips its round
@@ -833,6 +874,21 @@ static std::vector<uint32_t> crypt_program(int variant, size_t len) {
 
 static bool crypt_variant_ok(int variant) { return variant == P252_CRYPT_STREAM || variant == P252_CRYPT_DUPLEX; }
 
+// the sponge-call table of (variant, len) on the device (kept until another one is asked for)
+static int prepare_prog(p252_ctx* ctx, int variant, size_t len) {
+    if (ctx->prog_variant == variant && ctx->prog_len == len) return P252_OK;
+    const std::vector<uint32_t> prog = crypt_program(variant, len);
+    // the previous program may still be read by a kernel in flight on another stream: drain before replacing it
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    int rc = ensure(ctx, (void**)&ctx->d_prog, &ctx->d_prog_cap, prog.size() * sizeof(uint32_t));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prog, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->prog_variant = variant;
+    ctx->prog_len = len;
+    ctx->prog_calls = (unsigned)prog.size();
+    return P252_OK;
+}
+
 static int crypt_device(p252_ctx* ctx, int variant, bool decrypt, const uint64_t tag[4], const void* d_in, const void* d_secrets,
                         const void* d_nonces, size_t len, void* d_out, void* d_ok, size_t n, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
@@ -845,17 +901,8 @@ static int crypt_device(p252_ctx* ctx, int variant, bool decrypt, const uint64_t
     if (misaligned(d_in) || misaligned(d_secrets) || misaligned(d_nonces) || misaligned(d_out)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    if (ctx->prog_variant != variant || ctx->prog_len != len) {
-        const std::vector<uint32_t> prog = crypt_program(variant, len);
-        // the previous program may still be read by a kernel in flight on another stream: drain before replacing it
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        int rc = ensure(ctx, (void**)&ctx->d_prog, &ctx->d_prog_cap, prog.size() * sizeof(uint32_t));
-        if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpy(ctx->d_prog, prog.data(), prog.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        ctx->prog_variant = variant;
-        ctx->prog_len = len;
-        ctx->prog_calls = (unsigned)prog.size();
-    }
+    int rc = prepare_prog(ctx, variant, len);
+    if (rc) return rc;
     HIP_TRY(ctx, launch_crypt(decrypt, ctx->d_tab, tag_arg(tag), d_in, d_secrets, d_nonces, (unsigned)len, d_out, d_ok, n, ctx->d_prog,
                               ctx->prog_calls, st));
     return P252_OK;
@@ -884,20 +931,22 @@ static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t t
         const size_t in_stride = (decrypt ? len + 1 : len) * 32, out_stride = (decrypt ? len : len + 1) * 32;
         const size_t chunk = staging_chunk_items(in_stride + out_stride + 96);
         if (n >= 2 * chunk && len < 0x1ffffff0u) {  // large batch: through the staging lanes, chunk by chunk
-            // upload the call table first (crypt_device does that on its first launch); a one-item launch is the cheapest way
+            // the call table is uploaded once, here; the lanes then only launch (no shared state, no lock, and a failure
+            // keeps its own HIP error string)
+            int rc0 = prepare_prog(ctx, variant, len);
+            if (rc0) return rc0;
+            const TagArg targ = tag_arg(tag);
+            const uint32_t* d_prog = ctx->d_prog;
+            const unsigned n_calls = ctx->prog_calls;
             std::vector<HostSpan> ins = {{reinterpret_cast<const char*>(in), nullptr, in_stride},
                                          {reinterpret_cast<const char*>(secrets), nullptr, 64},
                                          {reinterpret_cast<const char*>(nonces), nullptr, 32}};
             std::vector<HostSpan> outs = {{nullptr, reinterpret_cast<char*>(out), out_stride}};
             if (decrypt) outs.push_back({nullptr, reinterpret_cast<char*>(ok), 1});
-            std::mutex mu;
             return staged_run(ctx, n, chunk, ins, outs,
                               [&](const void* const* d_in, void* const* d_out, size_t, size_t cnt, hipStream_t st) {
-                                  // crypt_device validates, (re)uploads the program when (variant, len) changed — serialised — and launches
-                                  std::lock_guard<std::mutex> lk(mu);
-                                  const int rc2 = crypt_device(ctx, variant, decrypt, tag, d_in[0], d_in[1], d_in[2], len, d_out[0],
-                                                               decrypt ? d_out[1] : nullptr, cnt, st);
-                                  return rc2 == P252_OK ? hipSuccess : hipErrorUnknown;
+                                  return launch_crypt(decrypt, ctx->d_tab, targ, d_in[0], d_in[1], d_in[2], (unsigned)len, d_out[0],
+                                                      decrypt ? d_out[1] : nullptr, cnt, d_prog, n_calls, st);
                               });
         }
     }
@@ -988,8 +1037,34 @@ static int check_ctxs(p252_ctx* const* ctxs, size_t n_ctx) {
     for (size_t a = 0; a < n_ctx; ++a)  // a context is used by one thread at a time: no duplicates
         for (size_t b = a + 1; b < n_ctx; ++b)
             if (ctxs[a] == ctxs[b]) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "multi: the same context appears twice");
+    // one context per GPU is the point of these entry points: when the node has at least n_ctx devices, two contexts on the
+    // same device are a caller's mistake (every shard would land on one GPU).  Fewer devices than contexts — the
+    // single-GPU test configuration — is allowed.  P252_MULTI_ALLOW_SHARED_DEVICE=1 lifts the check.
+    static const bool allow_shared = [] {
+        const char* e = std::getenv("P252_MULTI_ALLOW_SHARED_DEVICE");
+        return e && e[0] == '1';
+    }();
+    if (!allow_shared && (size_t)p252_device_count() >= n_ctx)
+        for (size_t a = 0; a < n_ctx; ++a)
+            for (size_t b = a + 1; b < n_ctx; ++b)
+                if (ctxs[a]->device == ctxs[b]->device)
+                    return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT,
+                                "multi: contexts " + std::to_string(a) + " and " + std::to_string(b) + " are bound to the same device although the node has one per context");
     return P252_OK;
 }
+
+// for the duration of one multi call every context works within its share of the CPU budget
+struct LaneBudgetScope {
+    p252_ctx* const* ctxs;
+    size_t n;
+    LaneBudgetScope(p252_ctx* const* c, size_t n_ctx) : ctxs(c), n(n_ctx) {
+        const int per = staging_lanes_per_ctx(n_ctx);
+        for (size_t t = 0; t < n; ++t) ctxs[t]->lane_budget = per;
+    }
+    ~LaneBudgetScope() {
+        for (size_t t = 0; t < n; ++t) ctxs[t]->lane_budget = 0;
+    }
+};
 
 int p252_hash_batch_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
                           size_t out_len, uint64_t* out, size_t n) {
@@ -1000,6 +1075,7 @@ int p252_hash_batch_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t ta
     if (!tag || !in || !out) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "hash: NULL buffer");
     // contiguous shards, sizes differing by at most one item
     const size_t base = n / n_ctx, rem = n % n_ctx;
+    LaneBudgetScope budget(ctxs, n_ctx);
     return for_each_ctx(ctxs, n_ctx, [&](size_t t) {
         const size_t lo = t * base + (t < rem ? t : rem), cnt = base + (t < rem ? 1 : 0);
         return p252_hash_batch(ctxs[t], tag, in + lo * in_len * 4, in_len, out_len, out + lo * out_len * 4, cnt);
@@ -1039,6 +1115,7 @@ int p252_merkle4_tree_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t 
                     "merkle_tree_multi: every device must own a complete subtree (n_leaves = n_ctx * 4^k)");
     const size_t m = n_leaves / n_ctx;
     std::vector<uint64_t> roots(4 * n_ctx);
+    LaneBudgetScope budget(ctxs, n_ctx);
     rc = for_each_ctx(ctxs, n_ctx, [&](size_t t) { return p252_merkle4_tree(ctxs[t], tag, leaves + t * m * 4, m, &roots[4 * t], nullptr); });
     if (rc) return rc;
     return tree_top(ctxs[0], tag, roots, n_ctx, root);
@@ -1073,6 +1150,20 @@ int p252_merkle4_tree_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const ui
     }
     return tree_top(ctxs[0], tag, roots, n_ctx, root);
 }
+
+// ------------------------------------------------------------------------------------------
+// measurement aids
+// ------------------------------------------------------------------------------------------
+int p252_clock_probe_device(p252_ctx* ctx, void* d_out6, unsigned spin_us, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (!d_out6 || (reinterpret_cast<uintptr_t>(d_out6) & 7u)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "clock_probe: d_out6 must be an 8-byte aligned device buffer of 6 x uint64");
+    if (spin_us > 1000000u) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "clock_probe: spin_us > 1 s");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_clock_probe(d_out6, spin_us * 100u, (hipStream_t)hip_stream));  // real-time counter: 100 MHz
+    return P252_OK;
+}
+
+int p252_staging_lanes(size_t n_ctx) { return staging_lanes_per_ctx(n_ctx ? n_ctx : 1); }
 
 // ------------------------------------------------------------------------------------------
 // constant-table exchange

@@ -23,7 +23,8 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
                           void* out, size_t n, hipStream_t st, unsigned arity = 4, size_t pad_lanes = 0);
 // incremental tree update: index[k] = leaf positions (u32); one level: node = index[i] >> shift, re-hashed from `children`
-hipError_t launch_scatter_scalars(const void* index, const void* values, void* dst, size_t k, hipStream_t st);
+// (index[i] >= n_dst: skipped, *n_bad incremented when n_bad != nullptr)
+hipError_t launch_scatter_scalars(const void* index, const void* values, void* dst, size_t k, size_t n_dst, void* n_bad, hipStream_t st);
 hipError_t launch_merkle4_update(const int32_t* tab, const TagArg& tag, const void* index, unsigned shift, const void* children,
                                  size_t n_children, void* out, size_t k, hipStream_t st);
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
@@ -42,5 +43,8 @@ hipError_t launch_to_canonical(const void* in, void* out, size_t n, hipStream_t 
 hipError_t launch_from_canonical(const void* in, void* out, void* ok, size_t n, const Digits9& r2, hipStream_t st);
 hipError_t launch_merkle4_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings,
                                const void* positions, unsigned depth, void* roots, size_t n, hipStream_t st);
+
+// measurement aid (bench.py): one wave samples the shader-clock and real-time counters around a sleep of spin_ticks (100 MHz ticks)
+hipError_t launch_clock_probe(void* out6, unsigned spin_ticks, hipStream_t st);
 
 }  // namespace p252

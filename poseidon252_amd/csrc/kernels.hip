@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __re
                                                              size_t n_children, Scalar32* __restrict__ out,
                                                              size_t n, unsigned arity, size_t lanes) {
     const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
-    if (lane >= lanes) return;  // (lanes is a multiple of 8: whole groups only)
+    if (lane >= lanes) return;  // (lanes is a multiple of LANES — launch_merkle4 rounds it up: whole groups only)
     const size_t idx = (unsigned)(lane / LANES) % (unsigned)n;  // (n <= 16,384 here: no 64-bit division)
     const int j = (int)(threadIdx.x & (LANES - 1));
     const int el = LANES == 8 ? (j < WIDTH ? j : WIDTH - 1) : j;  // the state element this lane brings: 0 = tag, 1..4 = children
@@ -211,9 +211,14 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __re
 // its leaf (node = leaf_index[i] >> shift) from the node's children in the level below.  Several updates under one node
 // compute it redundantly and store identical bytes.  One lane per update, or a lane group for k <= 8,192. ----
 __global__ void __launch_bounds__(P252_BLOCK) k_scatter_scalars(const uint32_t* __restrict__ index, const Scalar32* __restrict__ values,
-                                                                Scalar32* __restrict__ dst, size_t k) {
+                                                                Scalar32* __restrict__ dst, size_t k, size_t n_dst,
+                                                                unsigned* __restrict__ n_bad) {
     const size_t i = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (i >= k) return;
+    if (index[i] >= n_dst) {  // not a leaf of this tree: skipped (and counted, when the caller asked)
+        if (n_bad) atomicAdd(n_bad, 1u);
+        return;
+    }
     const uint4 lo = *reinterpret_cast<const uint4*>(values + i);
     const uint4 hi = *(reinterpret_cast<const uint4*>(values + i) + 1);
     *reinterpret_cast<uint4*>(dst + index[i]) = lo;
@@ -226,6 +231,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_update(const int32_t* __
     const size_t i = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (i >= k) return;
     const size_t node = index[i] >> shift;
+    if (node * 4 >= n_children) return;  // (an out-of-range leaf index: nothing above it belongs to this tree)
     E29 s[WIDTH];
 #pragma unroll
     for (int d = 0; d < NL; ++d) s[0].d[d] = tag.x0[d];
@@ -242,6 +248,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_update_coop(const int32_
     const size_t i = lane / 8;
     if (i >= k) return;
     const size_t node = index[i] >> shift;
+    if (node * 4 >= n_children) return;  // (whole group: the index is the group's)
     const int j = (int)(threadIdx.x & 7u);
     const int el = j < WIDTH ? j : WIDTH - 1;
     E29 mine = from_mont4(tag.w), unused;
@@ -628,6 +635,38 @@ __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path(con
     store_scalar(roots + idx, cur);
 }
 
+// ---- shader-clock probe: a measurement aid for bench.py, not part of the hashing path.  ONE wave reads the shader-clock
+// counter (s_memtime) and the constant-rate real-time counter (s_memrealtime, 100 MHz on MI300-class parts) before and
+// after sleeping for `spin_ticks` real-time ticks: (memtime delta) / (realtime delta) x 100 MHz = the shader clock over
+// that interval.  Launched on a second stream while the hashing kernels run it shares their CUs (32 VGPRs: it fits beside
+// three resident digest waves), so the figure is the clock UNDER LOAD — what GRBM_GUI_ACTIVE / duration gives in a
+// rocprofv3 --pmc pass (profiles/r02_pmc_k_merkle4.txt), but inside an ordinary run.  A chain of 1,024 dependent v_add_u32 is
+// timed with the same counter as a plausibility check (a fixed number of cycles per add whatever the clock).
+// out[6] = {memtime0, realtime0, memtime after the chain, memtime1, realtime1, chain result}. ----
+__global__ void __launch_bounds__(64) k_clock_probe(uint64_t* __restrict__ out, unsigned spin_ticks) {
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t m0 = __builtin_amdgcn_s_memtime();
+    uint32_t x = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 1024; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(x));
+    const uint64_t mc = __builtin_amdgcn_s_memtime();
+    uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+    while (r1 - r0 < (uint64_t)spin_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const uint64_t m1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = m0;
+        out[1] = r0;
+        out[2] = mc;
+        out[3] = m1;
+        out[4] = r1;
+        out[5] = x;
+    }
+}
+
 }  // namespace p252
 
 // ---------------------------------------------------------------------------------------------
@@ -667,8 +706,10 @@ hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* chi
     // launches of at most one wave per SIMD with 8 (4) lanes per node: the cooperative low-latency builds
     if (n <= coop_max_nodes() && n * 4 <= (size_t)65536) {
         const bool eight = n * 8 <= (size_t)65536;
-        const size_t want = n * (eight ? 8 : 4);
-        const size_t lanes = want < pad_lanes ? pad_lanes : want;
+        const size_t group = eight ? 8 : 4;
+        const size_t want = n * group;
+        // whole groups only: a partial last group would exchange with lanes that have already left the kernel
+        const size_t lanes = ((want < pad_lanes ? pad_lanes : want) + group - 1) & ~(group - 1);
         if (eight)
             hipLaunchKernelGGL(k_merkle4_coop<8>, dim3(grid_for(lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
                                static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, lanes);
@@ -700,10 +741,10 @@ hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* chi
     return hipGetLastError();
 }
 
-hipError_t launch_scatter_scalars(const void* index, const void* values, void* dst, size_t k, hipStream_t st) {
+hipError_t launch_scatter_scalars(const void* index, const void* values, void* dst, size_t k, size_t n_dst, void* n_bad, hipStream_t st) {
     if (k == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_scalars, dim3(grid_for(k)), dim3(P252_BLOCK), 0, st, static_cast<const uint32_t*>(index),
-                       static_cast<const Scalar32*>(values), static_cast<Scalar32*>(dst), k);
+                       static_cast<const Scalar32*>(values), static_cast<Scalar32*>(dst), k, n_dst, static_cast<unsigned*>(n_bad));
     return hipGetLastError();
 }
 
@@ -782,6 +823,11 @@ hipError_t launch_from_canonical(const void* in, void* out, void* ok, size_t n, 
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_from_canonical, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, static_cast<const Scalar32*>(in),
                        static_cast<Scalar32*>(out), static_cast<uint8_t*>(ok), n, r2);
+    return hipGetLastError();
+}
+
+hipError_t launch_clock_probe(void* out6, unsigned spin_ticks, hipStream_t st) {
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, st, static_cast<uint64_t*>(out6), spin_ticks);
     return hipGetLastError();
 }
 

@@ -227,10 +227,19 @@ class Context:
         assert d_scalars.is_cuda and d_out.is_cuda and self._nbytes(d_scalars) >= n * 32 and self._nbytes(d_out) >= n * 32
         self._check(_lib.lib().p252_truncate250_device(self._h, d_scalars.data_ptr(), d_out.data_ptr(), n, self._stream()))
 
-    def merkle4_update_device(self, tag, d_leaves, n_leaves, d_levels, d_indices, d_new_leaves, k, d_root=None):
+    def merkle4_update_device(self, tag, d_leaves, n_leaves, d_levels, d_indices, d_new_leaves, k, d_root=None, check=False):
         """incremental update of a stored tree: d_leaves[d_indices[i]] = d_new_leaves[i] (k distinct positions, int32/uint32
-        tensor) and every ancestor in d_levels (the layout merkle4_tree_device fills) re-hashed; d_root gets the new root"""
+        tensor) and every ancestor in d_levels (the layout merkle4_tree_device fills) re-hashed; d_root gets the new root.
+        Positions >= n_leaves are skipped by the kernels.  check=True (a debugging aid: it synchronises) raises ValueError
+        when the list holds an out-of-range or a repeated position."""
         tag = _as_scalars(tag).reshape(4)
+        if check and k:
+            import torch
+            idx = d_indices[:k].to(torch.int64) & 0xFFFFFFFF
+            if int(idx.max()) >= n_leaves:
+                raise ValueError("merkle4_update: position %d is outside the tree (%d leaves)" % (int(idx.max()), n_leaves))
+            if int(torch.unique(idx).numel()) != k:
+                raise ValueError("merkle4_update: the positions are not distinct")
         assert d_leaves.is_cuda and self._nbytes(d_leaves) >= n_leaves * 32
         assert n_leaves == 1 or (d_levels.is_cuda and self._nbytes(d_levels) >= _lib.lib().p252_merkle4_levels_len(n_leaves) * 32)
         if k:
@@ -275,6 +284,25 @@ class Context:
         self._check(_lib.lib().p252_merkle4_path_batch_device(
             self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), d_siblings.data_ptr() if depth else None,
             d_positions.data_ptr() if depth else None, depth, d_roots.data_ptr(), n, self._stream()))
+
+    # ---- measurement aid: the shader clock (bench.py) ----
+    def clock_probe(self, spin_us=1000, stream=None):
+        """launches the one-wave clock probe (p252_clock_probe_device) on `stream` (a torch.cuda.Stream; default: the current
+        one) and returns the device tensor it fills; read it with `clock_probe_result` after synchronising"""
+        import torch
+        stream = stream if stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):  # the buffer is zeroed on the probe's own stream: ordered before the kernel
+            out = torch.zeros(6, dtype=torch.int64, device="cuda:%d" % self.device)
+        self._check(_lib.lib().p252_clock_probe_device(self._h, out.data_ptr(), int(spin_us), ctypes.c_void_p(stream.cuda_stream)))
+        return out
+
+    @staticmethod
+    def clock_probe_result(t, realtime_hz=100e6):
+        """{shader_ghz, interval_us, cycles_per_dependent_add}: the shader clock over the probe's interval"""
+        m0, r0, mc, m1, r1, _ = [int(v) for v in t.cpu().tolist()]
+        ticks = max(1, r1 - r0)
+        return {"shader_ghz": (m1 - m0) / ticks * realtime_hz / 1e9, "interval_us": ticks / realtime_hz * 1e6,
+                "cycles_per_dependent_add": (mc - m0) / 1024.0}
 
     # ---- constant table exchange ----
     def tables_export(self):

@@ -21,12 +21,15 @@ def _check(ctxs, rc):
         _raise(rc, ctxs[0]._h if ctxs else None)
 
 
-def hash_batch_multi(ctxs, tag, messages, in_len, out_len):
+def hash_batch_multi(ctxs, tag, messages, in_len, out_len, out=None):
     """n messages of in_len scalars -> (n, out_len, 4); contiguous shards over `ctxs` (p252_hash_batch_multi)"""
     x = _as_scalars(messages).reshape(-1, in_len, 4) if in_len else _as_scalars(messages).reshape(0, 1, 4)
     n = x.shape[0]
     tag = _as_scalars(tag).reshape(4)
-    out = np.empty((n, max(out_len, 1), 4), dtype=np.uint64)
+    if out is None:
+        out = np.empty((n, max(out_len, 1), 4), dtype=np.uint64)
+    else:
+        assert out.dtype == np.uint64 and out.flags.c_contiguous and out.size == n * out_len * 4
     _check(ctxs, _lib.lib().p252_hash_batch_multi(_ctx_array(ctxs), len(ctxs), tag.ctypes.data_as(_u64p), x.ctypes.data_as(_u64p),
                                                    in_len, out_len, out.ctypes.data_as(_u64p), n))
     return out

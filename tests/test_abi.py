@@ -103,3 +103,22 @@ def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libposeidon252_hip.so")
     with pytest.raises(_lib.ExtensionMissing, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_abi_version_is_checked_by_the_binding():
+    """argument lists changed between library versions under unchanged names; the header carries a version, the
+    library reports the one it was built from, and the Python binding refuses a library of another version"""
+    from poseidon252_amd import _lib
+    text = open(HEADER).read()
+    ver = int(re.search(r"#define P252_ABI_VERSION (\d+)", text).group(1))
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.p252_abi_version.restype = ctypes.c_int
+    assert L.p252_abi_version() == ver == _lib.ABI_VERSION
+    assert _lib.lib().p252_abi_version() == ver  # (lib() would have raised ExtensionMissing on a mismatch)
+    # the staging-lane budget of the multi entry points: clamp(floor(cpus / n_ctx) - 1, 1, 3), no device needed
+    L.p252_staging_lanes.argtypes = [ctypes.c_size_t]
+    import bench
+    cpus = bench.usable_cpus()
+    for n_ctx in (2, 4, 8, 64):
+        assert L.p252_staging_lanes(n_ctx) == max(1, min(3, cpus // n_ctx - 1)), n_ctx
+    assert L.p252_staging_lanes(1) == L.p252_staging_lanes(0) == (2 if cpus < 4 else 3)

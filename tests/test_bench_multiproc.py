@@ -33,7 +33,7 @@ def _one_json_line(out):
 
 def test_bench_single_gpu_json_line(gpu_ctx):
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
-                                   "--log2n", "16", "--no-cpu-baseline"], cwd=ROOT, timeout=600)
+                                   "--log2n", "16", "--no-cpu-baseline", "--no-secondary"], cwd=ROOT, timeout=600)
     d = _one_json_line(out)
     for k in REQUIRED:
         assert k in d, k
@@ -41,13 +41,54 @@ def test_bench_single_gpu_json_line(gpu_ctx):
     assert d["value"] > 1e6 and d["scaling"] == "weak" and d["vs_baseline"] is None
     r = d["roofline"]
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["hbm"]["frac"] < 0.05
+    _check_clock(r)
+    assert "secondary" not in d  # (--no-secondary below: the default line carries them, see the next test)
+
+
+def _check_clock(r):
+    """the shader clock measured inside the run, and the fractions at it"""
+    c = r["clock"]
+    assert c["before"] and c["after"], c
+    for probe in (c["before"], c["after"]):
+        assert 1.0 < probe["shader_ghz"] < 2.6 and probe["interval_us"] > 100, probe
+    assert c["ghz_measured"] == pytest.approx((c["before"]["shader_ghz"] + c["after"]["shader_ghz"]) / 2)
+    e = r["executed"]
+    assert e["frac_at_measured_clock"] == pytest.approx(e["frac"] * 2.4 / c["ghz_measured"], rel=1e-6)
+    assert r["valu_issue"]["frac_at_measured_clock"] == pytest.approx(r["valu_issue"]["frac"] * 2.4 / c["ghz_measured"], rel=1e-6)
+
+
+def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
+    """the one command the driver runs times every BASELINE config — configs[1] as the primary keys, the tree
+    (configs[2]; configs[4] at 8 ranks) and the 42 -> 5 sponge (configs[3]) under "secondary", each with its own
+    self-consistency check, roofline, measured clock and (N = 1) oracle check of a sample.  Scaled down here."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "15",
+                                   "--secondary-log2n", "13"], cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
+    d = _one_json_line(out)
+    for k in REQUIRED:
+        assert k in d, k
+    assert "BASELINE configs[1]" in d["config"]["workload"] and d["self_consistency_ok"] is True
+    sec = d["secondary"]
+    assert sorted(sec) == ["sponge42", "tree"]
+    t, s = sec["tree"], sec["sponge42"]
+    assert "2^17-leaf arity-4 Merkle tree" in t["workload"]
+    assert t["units_per_gpu_per_step"] == 43691  # 2^17 leaves: 32768 + 8192 + ... + 8 + 2 + 1 nodes
+    assert s["units_per_gpu_per_step"] == 12 << 13 and "42 scalars -> 5 outputs" in s["workload"]
+    for w in (t, s):
+        assert w["self_consistency_ok"] is True and w["parity_sample_ok"] is True and w["n_gpus"] == 1 and w["ranks"] == 1
+        assert w["value"] == pytest.approx(w["units_per_gpu_per_step"] * w["steps"] / (w["ms_per_step"] * w["steps"] * 1e-3), rel=1e-6)
+        assert w["steps"] == 3 and w["roofline"]["executed"]["frac"] > 0 and w["roofline"]["launch_ms_mean"] > 0
+        _check_clock(w["roofline"])
+    assert t["roofline"]["kernel"] == "k_merkle4" and s["roofline"]["kernel"] == "k_sponge"
+    cb = d["cpu_baseline"]
+    assert cb["parity_samples"] == {"merkle4_digests": True, "tree": True, "sponge42": True} and cb["parity_sample_ok"] is True
+    assert cb["threads"] == cb["cores"] >= 1 and "cpu_quota" in cb and cb["cpus_visible"] >= 1
 
 
 def test_bench_cpu_baseline_leg_checks_gpu_sample(gpu_ctx):
     """default-shaped run at N=1 (small batch): the cpu_baseline leg times the oracle and verifies a
     sample of the GPU output that was just measured"""
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
-                                   "--log2n", "14"], cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
+                                   "--log2n", "14", "--no-secondary"], cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
     d = _one_json_line(out)
     cb = d["cpu_baseline"]
     assert cb["parity_sample_ok"] is True and cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e3
@@ -102,13 +143,22 @@ def test_bench_two_ranks_share_gpu_gloo(gpu_ctx):
     env = dict(os.environ, P252_BENCH_SHARE_GPU="1", P252_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--log2n", "16"]
+           "--warmup", "1", "--log2n", "16", "--secondary-log2n", "12"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.DEVNULL)
     d = _one_json_line(out)
     assert d["n_gpus"] == 2 and d["self_consistency_ok"] is True and "cpu_baseline" not in d
     assert "identical to local derivation: True" in d["config"]["constants"]
     # whole-job value = 2 ranks x units / max-over-ranks time
     assert d["value"] == pytest.approx(2 * d["config"]["units_per_gpu_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+    # the secondary workloads at N = 2: the tree is the configs[4] composition (subtree per rank, all-gather of the roots)
+    t, s = d["secondary"]["tree"], d["secondary"]["sponge42"]
+    assert t["n_gpus"] == 2 and t["ranks"] == 2 and t["collective_backend"] == "gloo" and "all-gather of 2 x 32-byte subtree roots" in t["exchange"]
+    assert "all-gather of 2 subtree roots" in t["workload"] and t["units_per_gpu_per_step"] == (4 ** 8 - 1) // 3 + 1
+    assert t["value"] == pytest.approx(2 * t["units_per_gpu_per_step"] * t["steps"] / (t["ms_per_step"] * t["steps"] * 1e-3), rel=1e-6)
+    assert s["ranks"] == 2 and s["exchange"] is None and s["units_per_gpu_per_step"] == 12 << 12
+    for w in (t, s):
+        assert w["self_consistency_ok"] is True and w["parity_sample_ok"] is None  # (the oracle leg exists at N = 1 only)
+        assert w["roofline"]["clock"]["ghz_measured"] > 1.0
 
 
 def test_bench_gpus_flag_launches_the_ranks_itself(gpu_ctx):

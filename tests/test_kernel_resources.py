@@ -66,20 +66,23 @@ def test_one_multiply_add_per_product(isa):
 
 @pytest.mark.gpu
 def test_throughput_floor(gpu_ctx):
-    """loose floor (the kernel measures ~3.0e8 perm/s on MI355X): catches order-of-magnitude regressions only"""
+    """floor at 4.0e8 digests/s (the kernel measures 4.5-4.8e8 on every MI355X box seen, driver-timed 4.50e8): a regression
+    of more than ~10 % fails (the old floor of 1.5e8 let a 60 % regression pass)"""
     import torch
     n = 1 << 20
     d_in = torch.randint(0, 2 ** 62, (n * 4, 4), dtype=torch.int64, device="cuda")
     d_out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     import numpy as np
     tag = np.arange(4, dtype=np.uint64)
-    for _ in range(2):
+    for _ in range(40):  # ~90 ms: an idle chip's clocks need ~25 ms of load to reach steady state
         gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
-    e1.record()
-    torch.cuda.synchronize()
-    rate = 5 * n / (e0.elapsed_time(e1) * 1e-3)
-    assert rate > 1.5e8, rate
+    best = 0.0
+    for _ in range(3):
+        e0.record()
+        for _ in range(20):
+            gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 20 * n / (e0.elapsed_time(e1) * 1e-3))
+    assert best > 4.0e8, best

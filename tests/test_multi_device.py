@@ -9,8 +9,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def ctxs(gpu_ctx):
+    import torch
     import poseidon252_amd as P
-    cs = [P.Context(0) for _ in range(8)]
+    # a single-GPU box: all on device 0 (allowed when the node has fewer devices than contexts); an 8-GPU node: one per GPU
+    nd = torch.cuda.device_count()
+    cs = [P.Context(t % nd) for t in range(8)]
     yield cs
     for c in cs:
         c.close()
@@ -50,12 +53,13 @@ def test_multi_device_resident_variants(gpu_ctx, ctxs, oracle_mod):
     tag = P.merkle4_tag()
     k, per = 4, 4 ** 6
     lv = oracle_mod.fill_random(31337, k * per)
-    d = [torch.from_numpy(lv[t * per:(t + 1) * per].view(np.int64)).cuda() for t in range(k)]
+    d = [torch.from_numpy(lv[t * per:(t + 1) * per].view(np.int64)).to("cuda:%d" % ctxs[t].device) for t in range(k)]
     assert np.array_equal(multi.merkle4_tree_multi_device(ctxs[:k], tag, d, per), oracle_mod.merkle4_tree(tag, lv)[0])
-    outs = [torch.empty((per // 4, 4), dtype=torch.int64, device="cuda") for _ in range(k)]
+    outs = [torch.empty((per // 4, 4), dtype=torch.int64, device="cuda:%d" % ctxs[t].device) for t in range(k)]
     multi.hash_batch_multi_device(ctxs[:k], tag, d, 4, 1, outs, [per // 4] * k)
-    torch.cuda.synchronize()
-    got = torch.cat(outs).cpu().numpy().view(np.uint64)
+    for t in range(k):
+        torch.cuda.synchronize(ctxs[t].device)
+    got = torch.cat([o.cpu() for o in outs]).numpy().view(np.uint64)
     assert np.array_equal(got, oracle_mod.hash_batch(tag, lv.reshape(-1, 4, 4), 4, 1).reshape(-1, 4))
 
 
@@ -74,3 +78,80 @@ def test_multi_argument_errors(gpu_ctx, ctxs, oracle_mod):
         multi.hash_batch_multi([ctxs[0], ctxs[0]], tag, lv[:8].reshape(2, 4, 4), 4, 1)  # a context twice
     with pytest.raises(P.InvalidIOPattern):
         multi.hash_batch_multi(ctxs[:2], tag, lv[:8].reshape(2, 4, 4), 4, 0)
+
+
+def test_multi_contexts_share_the_cpu_budget(gpu_ctx, ctxs, oracle_mod):
+    """8 contexts x the single-context default of 3 staging lanes is 24 workers + 8 drivers under the box's
+    16-CPU quota — the configuration the single-context sweep measured at half speed.  The multi entry points give every
+    context clamp(floor(usable CPUs / n_ctx) - 1, 1, 3) lanes: the worker-thread count stays within the budget and the
+    pageable host-to-host rate of 8 contexts is not below the single context's."""
+    import os
+    import threading
+    import time
+    import ctypes
+    import poseidon252_amd as P
+    from poseidon252_amd import multi, _lib
+    import bench
+    L = _lib.lib()
+    cpus = bench.usable_cpus()
+    per8 = L.p252_staging_lanes(8)
+    assert per8 == max(1, min(3, cpus // 8 - 1)) and L.p252_staging_lanes(1) == (2 if cpus < 4 else 3)
+    assert L.p252_staging_lanes(2) == max(1, min(3, cpus // 2 - 1))
+    tag = P.merkle4_tag()
+    n = 1 << 22
+    x = oracle_mod.fill_random(77, 4 * n).reshape(n, 4, 4)
+    out = np.empty((n, 1, 4), dtype=np.uint64)
+
+    def rate(fn, reps=3):
+        fn()  # staging buffers are allocated on first use
+        best = 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            best = max(best, n / (time.perf_counter() - t0))
+        return best
+    single = rate(lambda: gpu_ctx.hash_batch(tag, x, 4, 1, out=out))
+    ref = out.copy()
+    base_threads = len(os.listdir("/proc/self/task"))
+    peak = [0]
+    stop = threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            peak[0] = max(peak[0], len(os.listdir("/proc/self/task")))
+            time.sleep(0.002)
+    w = threading.Thread(target=watch)
+    w.start()
+    try:
+        eight = rate(lambda: multi.hash_batch_multi(ctxs, tag, x, 4, 1, out=out))
+    finally:
+        stop.set()
+        w.join()
+    assert np.array_equal(out, ref)
+    # threads the call added: 7 drivers (context 0 runs on the caller) + (lanes - 1) extra workers per context (+ the watcher)
+    added = peak[0] - base_threads
+    assert added <= 7 + 8 * (per8 - 1) + 1 + 2, (added, per8)
+    assert added < 24, added
+    print("host->host digests/s: 1 context %.3g, 8 contexts (device 0) %.3g, lanes per context %d, threads added %d" % (single, eight, per8, added))
+    assert eight >= 0.9 * single, (single, eight)
+
+
+def test_multi_refuses_shared_devices_when_the_node_has_enough(gpu_ctx, ctxs, oracle_mod):
+    """two contexts on one device are a caller's mistake when the node has a device per context; fewer devices than
+    contexts (this box, normally) is the allowed single-GPU configuration"""
+    import torch
+    import poseidon252_amd as P
+    from poseidon252_amd import multi
+    tag = P.merkle4_tag()
+    x = oracle_mod.fill_random(5, 8).reshape(2, 4, 4)
+    nd = torch.cuda.device_count()
+    a, b = P.Context(0), P.Context(0)
+    try:
+        if nd >= 2:
+            with pytest.raises(ValueError):
+                multi.hash_batch_multi([a, b], tag, x, 4, 1)
+        else:
+            assert np.array_equal(multi.hash_batch_multi([a, b], tag, x, 4, 1), gpu_ctx.hash_batch(tag, x, 4, 1))
+    finally:
+        a.close()
+        b.close()

@@ -172,3 +172,51 @@ def test_incremental_tree_update(gpu_ctx, oracle_mod, n_leaves, k):
     assert np.array_equal(d_leaves.cpu().numpy().view(np.uint64), updated)
     assert np.array_equal(d_levels.cpu().numpy().view(np.uint64)[:total], o_levels)
     assert np.array_equal(d_root.cpu().numpy().view(np.uint64), o_root)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_total", [40, 20000])  # the lane-group kernel (k <= 8,192) and the one-lane kernel
+def test_incremental_update_skips_out_of_range_positions(gpu_ctx, oracle_mod, k_total):
+    """ADVICE r2: a position >= n_leaves used to be undefined behaviour (a store outside the leaves).  It is skipped now;
+    p252_merkle4_update_checked_device also counts the skipped positions; the Python wrapper's check=True raises before
+    launching.  The tree afterwards equals a fresh build over the in-range updates only."""
+    import ctypes
+    import torch
+    from poseidon252_amd import _lib
+    n_leaves = 5003
+    tag = oracle_mod.tag(0, [4], 1)
+    leaves = oracle_mod.fill_random(11, n_leaves)
+    total = oracle_mod.levels_total(n_leaves)
+    # guard scalars behind the leaves: an out-of-range store would land there
+    d_buf = torch.from_numpy(np.concatenate([leaves, np.full((64, 4), 0x5A5A5A5A5A5A5A5A, dtype=np.uint64)]).view(np.int64).copy()).cuda()
+    d_levels = torch.zeros((total, 4), dtype=torch.int64, device="cuda")
+    d_root = torch.zeros(4, dtype=torch.int64, device="cuda")
+    gpu_ctx.merkle4_tree_device(tag, d_buf, n_leaves, d_root, d_levels)
+    rng = np.random.default_rng(k_total)
+    good = rng.permutation(n_leaves)[:min(k_total - 5, n_leaves // 2)].astype(np.int64)
+    bad = np.array([n_leaves, n_leaves + 1, n_leaves + 40, 2 ** 31 + 5, 2 ** 32 - 1], dtype=np.int64)
+    idx = np.concatenate([good[:3], bad[:2], good[3:], bad[2:]])
+    k = idx.shape[0]
+    new = oracle_mod.fill_random(500 + k, k)
+    d_idx = torch.from_numpy(idx.astype(np.uint32).view(np.int32)).cuda()
+    d_new = torch.from_numpy(new.view(np.int64).copy()).cuda()
+    with pytest.raises(ValueError):
+        gpu_ctx.merkle4_update_device(tag, d_buf, n_leaves, d_levels, d_idx, d_new, k, d_root, check=True)
+    with pytest.raises(ValueError):  # a repeated position
+        gpu_ctx.merkle4_update_device(tag, d_buf, n_leaves, d_levels, torch.zeros(2, dtype=torch.int32, device="cuda"), d_new, 2, d_root, check=True)
+    d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    t = np.ascontiguousarray(tag, dtype=np.uint64)
+    rc = _lib.lib().p252_merkle4_update_checked_device(gpu_ctx._h, t.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), d_buf.data_ptr(), n_leaves,
+                                                       d_levels.data_ptr(), d_idx.data_ptr(), d_new.data_ptr(), k, d_root.data_ptr(),
+                                                       d_bad.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(d_bad.item()) == bad.shape[0]
+    updated = leaves.copy()
+    in_range = idx < n_leaves
+    updated[idx[in_range]] = new[in_range]
+    o_root, o_levels, _ = oracle_mod.merkle4_tree(tag, updated, want_levels=True)
+    got = d_buf.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got[:n_leaves], updated) and (got[n_leaves:] == 0x5A5A5A5A5A5A5A5A).all()
+    assert np.array_equal(d_levels.cpu().numpy().view(np.uint64), o_levels)
+    assert np.array_equal(d_root.cpu().numpy().view(np.uint64), o_root)

@@ -1,12 +1,28 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV passes (gpurun_out/pmc_*/pmc_counter_collection.csv) for one kernel.
-usage: pmc_summary.py <kernel-substring> <units_per_launch> [--bytes-per-unit B] <dir> [<dir> ...]
--> text on stdout, JSON on fd 3 if open.  units = permutations per launch; B = algorithmic bytes per permutation."""
+usage: pmc_summary.py <kernel-substring> <units_per_launch> [--bytes-per-unit B] [--per-step] <dir> [<dir> ...]
+-> text on stdout, JSON on fd 3 if open.  units = permutations per launch; B = algorithmic bytes per permutation.
+--per-step: a step is SEVERAL launches of different sizes (a tree build: one launch per level, several kernel builds):
+every dispatch whose name contains the substring is summed, and the sum is divided by the number of steps (= dispatches of
+the largest grid, the first level); run the workload with --no-check so that nothing but full steps is in the trace.
+The JSON records the SHA-256 of the kernel sources the pass was collected from (bench.py refuses a file that belongs to
+other sources)."""
 import collections
 import csv
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("kernels.hip", "fr29.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h")  # = bench.py's
+
+
+def kernel_sources_sha256():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "poseidon252_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def main():
@@ -16,24 +32,38 @@ def main():
     if rest and rest[0] == "--bytes-per-unit":
         bpu = float(rest[1])
         rest = rest[2:]
+    per_step = False
+    if rest and rest[0] == "--per-step":
+        per_step = True
+        rest = rest[1:]
     agg = collections.defaultdict(list)
     durs = []
     rows = []
     for d in rest:
         rows += [r for r in csv.DictReader(open(os.path.join(d, "pmc_counter_collection.csv"))) if kern in r["Kernel_Name"]]
     full = max(int(r["Grid_Size"]) for r in rows)  # the timed launches; smaller self-check launches of the same kernel are left out
+    n_full = collections.Counter()
     for r in rows:
         if int(r["Grid_Size"]) == full:
+            n_full[r["Counter_Name"]] += 1
+        if int(r["Grid_Size"]) == full or per_step:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
-                durs.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
-            meta = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
-    avg = {k: sum(v) / len(v) for k, v in agg.items()}
-    print("# rocprofv3 --pmc summary for kernel *%s* (avg per dispatch over %d dispatches, separate passes per counter group)" % (kern, len(next(iter(agg.values())))))
+            if int(r["Grid_Size"]) == full:
+                if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                    durs.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+                meta = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
+    if per_step:
+        avg = {k: sum(v) / n_full[k] for k, v in agg.items()}
+        print("# rocprofv3 --pmc summary for the kernels *%s* of one STEP (all launches of a step summed; %d steps; separate passes per counter group)" % (kern, next(iter(n_full.values()))))
+    else:
+        avg = {k: sum(v) / len(v) for k, v in agg.items()}
+        print("# rocprofv3 --pmc summary for kernel *%s* (avg per dispatch over %d dispatches, separate passes per counter group)" % (kern, len(next(iter(agg.values())))))
     print("# grid=%s wg=%s vgpr=%s sgpr=%s scratch=%s lds=%s ; units (permutations) per launch = %d" % (meta + (units,)))
     for k in sorted(avg):
         print("%-24s %.6g" % (k, avg[k]))
-    out = {"kernel": kern, "units_per_launch": units, "counters": avg, "algorithmic_bytes_per_unit": bpu}
+    out = {"kernel": kern, "units_per_launch": units, "counters": avg, "algorithmic_bytes_per_unit": bpu, "per_step": per_step,
+           "kernel_sources_sha256": kernel_sources_sha256()}
+    print("# kernel sources sha256 %s" % out["kernel_sources_sha256"][:16])
     if durs:
         durs.sort()
         out["avg_duration_us"] = sum(durs) / len(durs)
@@ -51,7 +81,7 @@ def main():
         print("hbm_bytes_per_launch                 %.6g   (algorithmic: %.6g = %.4g B x units)" % (rd + wr, bpu * units, bpu))
         print("traffic / algorithmic                %.3f" % ((rd + wr) / (bpu * units)))
         out["traffic_ratio"] = (rd + wr) / (bpu * units)
-    if "SQ_INSTS_VALU" in avg and "SQ_WAVES" in avg:
+    if "SQ_INSTS_VALU" in avg and "SQ_WAVES" in avg and not per_step:
         per_wave = avg["SQ_INSTS_VALU"] / avg["SQ_WAVES"]
         out["valu_insts_per_wave"] = per_wave
         print("VALU instructions per wave (= per 64 permutations)   %.0f" % per_wave)

@@ -11,6 +11,8 @@ WL=${1:-merkle4_digests}
 shift || true
 PASSES=${*:-valu itype wait fetch write ktrace}
 mkdir -p "$O/summaries"
+EXTRA=""
+[ "$WL" = tree ] && EXTRA="--no-check"  # a tree step is 12 launches: nothing but full builds may be in the trace (pmc_summary --per-step)
 cd /tmp && export TMPDIR=/tmp
 counters() {
     case $1 in
@@ -19,17 +21,23 @@ counters() {
         wait)  echo SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SMEM ;;
         fetch) echo FETCH_SIZE ;;
         write) echo WRITE_SIZE ;;
+        # stall attribution
+        stall)  echo SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES ;;
+        ifetch) echo SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INST_CYCLES_SMEM SQ_WAVES ;;
+        icache) echo SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES SQC_TC_INST_REQ SQC_TC_STALL ;;
+        dcache) echo SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_DCACHE_BUSY_CYCLES SQC_TC_DATA_READ_REQ ;;
+        thread) echo SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_CYCLES GRBM_GUI_ACTIVE ;;
     esac
 }
 for p in $PASSES; do
     if [ "$p" = ktrace ]; then
         rm -rf "$O/ktrace_$WL"
         timeout 300 rocprofv3 --kernel-trace --stats -d "$O/ktrace_$WL" -o kt -- \
-            python "$ROOT/bench.py" --workload "$WL" --no-cpu-baseline > "$O/ktrace_$WL.log" 2>&1
+            python "$ROOT/bench.py" --workload "$WL" --no-cpu-baseline $EXTRA > "$O/ktrace_$WL.log" 2>&1
     else
         rm -rf "$O/pmc_${WL}_$p"
         timeout 300 rocprofv3 --pmc $(counters $p) --kernel-trace --output-format csv -d "$O/pmc_${WL}_$p" -o pmc -- \
-            python "$ROOT/bench.py" --workload "$WL" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_${WL}_$p.log" 2>&1
+            python "$ROOT/bench.py" --workload "$WL" --steps 5 --warmup 1 --no-cpu-baseline $EXTRA > "$O/pmc_${WL}_$p.log" 2>&1
     fi
     echo "pass $p rc=$?"
 done
@@ -40,10 +48,12 @@ case $WL in  # dominant kernel, permutations per launch, algorithmic bytes per p
     sponge42) K=k_sponge; U=$((12 * U20)); B=125.3333 ;;
     openings) K=k_merkle4_path; U=$((12 * U20)); B=99.3333 ;;
     encrypt) K=k_crypt; U=$((2 * U20)); B=128 ;;
+    tree) K=k_merkle4; U=5592405; B=96.0000057; PS=--per-step; NAME=tree ;;
     *) K=k_merkle4; U=$U20; B=96 ;;
 esac
+PS=${PS:-}; NAME=${NAME:-$K}
 dirs=""; for d in "$O"/pmc_${WL}_*; do [ -f "$d/pmc_counter_collection.csv" ] && dirs="$dirs $d"; done
-[ -n "$dirs" ] && python tools/pmc_summary.py $K $U --bytes-per-unit $B $dirs > "$O/summaries/pmc_$K.txt" 3> "$O/summaries/pmc_$K.json"
+[ -n "$dirs" ] && python tools/pmc_summary.py $K $U --bytes-per-unit $B $PS $dirs > "$O/summaries/pmc_$NAME.txt" 3> "$O/summaries/pmc_$NAME.json"
 db=$(find "$O/ktrace_$WL" -name "*.db" 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocprof_summary.py "$db" "bench.py --workload $WL" > "$O/summaries/ktrace_$WL.txt"
 ls "$O/summaries"
