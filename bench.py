@@ -406,8 +406,10 @@ def make_workload(E, wl, log2n):
             torch.cuda.synchronize()
             return bool(torch.equal(again, d_out[lo:lo + cnt]))
         if wl == "tree":
-            # subtree composition: the tree over the 4 quarter-tree roots is the tree's root
-            quarters = torch.stack([P.merkle4_tree(d_in[i * (n // 4):(i + 1) * (n // 4)], tag=tag, ctx=ctx) for i in range(4)])
+            # subtree composition: the tree over the roots of the 4 quarter trees (4^k leaves: complete subtrees; 2 half
+            # trees when the leaf count is 2 x 4^k) is the tree's root
+            parts = 4 if log2n % 2 == 0 else 2
+            quarters = torch.stack([P.merkle4_tree(d_in[i * (n // parts):(i + 1) * (n // parts)], tag=tag, ctx=ctx) for i in range(parts)])
             top = P.merkle4_tree(quarters.contiguous(), tag=tag, ctx=ctx)
             ref = torch.empty(4, dtype=torch.int64, device=dev)
             ctx.merkle4_tree_device(tag, d_in, n, ref, None)

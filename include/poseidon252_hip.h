@@ -259,8 +259,9 @@ int p252_from_bytes(const uint8_t* bytes, uint64_t* scalars, uint8_t* ok, size_t
  * of its own while hashing kernels run it measures the clock under that load. */
 int p252_clock_probe_device(p252_ctx* ctx, void* d_out6, unsigned spin_us, void* hip_stream);
 /* staging lanes (worker threads) each context uses for pageable host buffers when n_ctx contexts are driven at once by a
- * p252_*_multi call: clamp(floor(usable CPUs / n_ctx) - 1, 1, 3); n_ctx <= 1: the single-context default (3; 2 below four
- * CPUs).  P252_HOST_LANES overrides both. */
+ * p252_*_multi call: clamp(floor(usable CPUs / n_ctx), 1, 3) — the driver thread of a context is its first lane, so the
+ * call never runs more workers than the process has CPUs (min(affinity, cgroup quota)); n_ctx <= 1: the single-context
+ * default (3; 2 below four CPUs).  P252_HOST_LANES overrides both. */
 int p252_staging_lanes(size_t n_ctx);
 
 /* library/version introspection */

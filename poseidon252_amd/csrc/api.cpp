@@ -374,13 +374,17 @@ static int staging_lanes_wanted() {
     return cpu_budget() < 4 ? 2 : 3;
 }
 
-// staging lanes per context when n_ctx contexts are driven at once (p252_*_multi: one driver thread per context, each a
-// staging lane itself, plus its extra lanes): the contexts SHARE the CPU budget — 8 contexts x 3 lanes under a 16-CPU quota
-// is the 24-worker configuration the single-context sweep measured at half speed.
+// staging lanes per context when n_ctx contexts are driven at once (p252_*_multi: one driver thread per context, which
+// is that context's first lane, plus its extra lanes): the contexts SHARE the CPU budget — 8 contexts x 3 lanes under a
+// 16-CPU quota is the 24-worker configuration the single-context sweep measured at half speed.
+// A lane is host-memcpy work: ONE worker moves 1.66e8 digests/s (26.5 GB/s, profiles/r03_host_path_multi.txt: one context,
+// one lane), a GPU takes 4.1e8, so a GPU wants 2.5 workers and the whole budget is worth using: lanes = floor(CPUs / n_ctx),
+// at most the single-context optimum of 3, at least 1 — never more workers than CPUs (they sleep on blocking-sync events
+// while their chunks are in flight; only the copies cost CPU time).
 static int staging_lanes_per_ctx(size_t n_ctx) {
     if (staging_lanes_env()) return staging_lanes_env();
     if (n_ctx <= 1) return staging_lanes_wanted();
-    int per = (int)(cpu_budget() / (double)n_ctx) - 1;
+    int per = (int)(cpu_budget() / (double)n_ctx);
     return per < 1 ? 1 : (per > 3 ? 3 : per);
 }
 

@@ -35,6 +35,34 @@ __device__ __forceinline__ E29 load_scalar(const Scalar32* __restrict__ p) {
     return from_mont4(w);
 }
 
+// a record as it lies in memory (two 16-byte halves): fetched whole cache lines at a time by the sponge and opening
+// kernels, kept raw across a permutation and converted where it is consumed
+struct Raw32 {
+    uint4 lo, hi;
+};
+__device__ __forceinline__ Raw32 load_raw(const Scalar32* __restrict__ p) {
+    Raw32 r;
+    r.lo = *reinterpret_cast<const uint4*>(p);
+    r.hi = *(reinterpret_cast<const uint4*>(p) + 1);
+    return r;
+}
+__device__ __forceinline__ Raw32 raw_zero() {
+    Raw32 r;
+    r.lo = make_uint4(0u, 0u, 0u, 0u);
+    r.hi = r.lo;
+    return r;
+}
+__device__ __forceinline__ Raw32 raw_select(bool first, const Raw32& a, const Raw32& b) {  // per-lane: first ? a : b
+    Raw32 r;
+    r.lo = make_uint4(first ? a.lo.x : b.lo.x, first ? a.lo.y : b.lo.y, first ? a.lo.z : b.lo.z, first ? a.lo.w : b.lo.w);
+    r.hi = make_uint4(first ? a.hi.x : b.hi.x, first ? a.hi.y : b.hi.y, first ? a.hi.z : b.hi.z, first ? a.hi.w : b.hi.w);
+    return r;
+}
+__device__ __forceinline__ E29 raw_to_e29(const Raw32& r) {
+    const uint32_t w[8] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w};
+    return from_mont4(w);
+}
+
 __device__ __forceinline__ void store_scalar(Scalar32* __restrict__ p, const E29& e) {
     uint32_t w[8];
     to_mont4(e, w);
@@ -348,11 +376,19 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path_coop(const int32_t*
 
 // ---- generic sponge: n messages, same (in_len, out_len).  dusk-safe mechanics:
 // absorb 4 elements per permutation into state[1..4]; first squeeze always permutes; 4 outputs per
-// permutation.  One inlined permutation call site. ----
-__global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict__ tab, TagArg tag,
-                                                       const Scalar32* __restrict__ in, unsigned in_len,
-                                                       unsigned out_len, Scalar32* __restrict__ out,
-                                                       size_t n) {
+// permutation.  One inlined permutation call site.
+// HBM reads ("coalesced HBM loads of batched input scalars", north_star): a lane's message is in_len x 32 contiguous bytes,
+// so an absorb block (4 scalars = 128 B) is exactly one cache line — when the message starts on a line boundary.  With an even
+// in_len (config 4: 42 scalars = 10.5 lines) every other message starts in mid-line; fetched block by block, each of its
+// blocks straddles two lines and every line is fetched twice, a permutation (0.18 ms) apart — by then it has left the
+// caches: 1.19 x the algorithmic traffic (profiles/r02_pmc_k_sponge.txt).  LINES = true: every lane fetches WHOLE LINES —
+// a lane whose message starts sh = 2 scalars into a line reads scalars 4 it + 2 .. 4 it + 5 at block it, absorbs the two
+// carried over from the previous fetch plus the first two of this one and carries the other two (16 VGPRs, raw) across the
+// permutation.  Every line is touched once (the half lines at a message's ends excepted).  Taken when in_len is even and
+// the array is 64-byte aligned (kernel-uniform); otherwise block by block as before. ----
+template <bool LINES>
+__device__ __forceinline__ void sponge_body(const int32_t* __restrict__ tab, const TagArg& tag, const Scalar32* __restrict__ in,
+                                            unsigned in_len, unsigned out_len, Scalar32* __restrict__ out, size_t n) {
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (idx >= n) return;
     const Scalar32* my_in = in + idx * in_len;
@@ -363,18 +399,38 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
     for (int k = 0; k < 4; ++k) s[1 + k] = e29_zero();
     const unsigned absorb_blocks = (in_len + 3) / 4;
     const unsigned squeeze_blocks = (out_len + 3) / 4;
-    // block 0 of the message
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if ((unsigned)k < in_len) s[1 + k] = load_scalar(my_in + k);
+    // my message starts `sh` scalars into its 128-byte line: 0, or 2 for every other message of an even in_len
+    const unsigned sh = LINES ? (unsigned)((reinterpret_cast<uintptr_t>(my_in) >> 5) & 3u) : 0u;
+    const bool shifted = sh != 0;
+    Raw32 c0 = raw_zero(), c1 = raw_zero();
+    if (LINES) {  // the half line at the head of a shifted message (unshifted lanes: the same line block 0 fetches next)
+        if (0 < in_len) c0 = load_raw(my_in);
+        if (1 < in_len) c1 = load_raw(my_in + 1);
+    }
 #pragma unroll 1
-    for (unsigned it = 1; it < absorb_blocks + squeeze_blocks; ++it) {
-        hades_permute<0x1fu>(s, tab);
+    for (unsigned it = 0; it < absorb_blocks + squeeze_blocks; ++it) {
+        if (it > 0) hades_permute<0x1fu>(s, tab);
         if (it < absorb_blocks) {
+            if (LINES) {
+                Raw32 L[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned e = it * 4 + k;
-                if (e < in_len) add_e(s[1 + k], load_scalar(my_in + e));  // Safe::add, scalar.rs:33-35
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned pos = it * 4 + sh + j;
+                    L[j] = pos < in_len ? load_raw(my_in + pos) : raw_zero();
+                }
+                const Raw32 e[4] = {raw_select(shifted, c0, L[0]), raw_select(shifted, c1, L[1]), raw_select(shifted, L[0], L[2]),
+                                    raw_select(shifted, L[1], L[3])};
+                c0 = L[2];
+                c1 = L[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (it * 4 + k < in_len) add_e(s[1 + k], raw_to_e29(e[k]));  // Safe::add, scalar.rs:33-35 (block 0: 0 + e)
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned e = it * 4 + k;
+                    if (e < in_len) add_e(s[1 + k], load_scalar(my_in + e));  // Safe::add, scalar.rs:33-35
+                }
             }
         } else {
             const unsigned ob = (it - absorb_blocks) * 4;
@@ -383,6 +439,18 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict
                 if (ob + k < out_len) store_scalar(my_out + ob + k, s[1 + k]);
         }
     }
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge(const int32_t* __restrict__ tab, TagArg tag,
+                                                       const Scalar32* __restrict__ in, unsigned in_len,
+                                                       unsigned out_len, Scalar32* __restrict__ out,
+                                                       size_t n) {
+    sponge_body<false>(tab, tag, in, in_len, out_len, out, n);
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge_lines(const int32_t* __restrict__ tab, TagArg tag,
+                                                             const Scalar32* __restrict__ in, unsigned in_len,
+                                                             unsigned out_len, Scalar32* __restrict__ out,
+                                                             size_t n) {
+    sponge_body<true>(tab, tag, in, in_len, out_len, out, n);
 }
 
 // ---- batched encryption / decryption (src/encryption.rs:62-95 -> dusk_safe::encrypt / decrypt) ----
@@ -602,25 +670,87 @@ __global__ void __launch_bounds__(P252_BLOCK) k_from_canonical(const Scalar32* i
 // ---- batched Merkle opening: recompute the root from a leaf and its sibling path (arity 4).
 // Per level l the node hashed is Hash::digest(Merkle4, children) with children[pos[l]] = current value
 // and the 3 siblings in the remaining slots in order; depth sequential permutations per lane.
-// Layout: leaves[n], siblings[n][depth][3], positions[n][depth] (u8, 0..3), roots[n]. ----
-__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path(const int32_t* __restrict__ tab, TagArg tag,
-                                                             const Scalar32* __restrict__ leaves,
-                                                             const Scalar32* __restrict__ siblings,
-                                                             const uint8_t* __restrict__ positions,
-                                                             unsigned depth, Scalar32* __restrict__ roots,
-                                                             size_t n) {
+// Layout: leaves[n], siblings[n][depth][3], positions[n][depth] (u8, 0..3), roots[n].
+// HBM reads: a level's sibling triple is 96 B of the lane's depth x 96 contiguous bytes, so three of every four triples
+// straddle a cache line, and every line is fetched twice, a permutation apart; the position bytes (one per level, 12 lanes
+// to a line) once per level: 1.31 x the algorithmic traffic (profiles/r02_pmc_k_merkle4_path.txt).  LINES = true (depth a
+// multiple of 4 and both arrays line-aligned, kernel-uniform — every lane's path then starts on a line boundary and the
+// pattern is the same for all lanes): whole lines, one per level for three levels out of four (level 4 j + 3 needs none);
+// the scalars a later level needs wait in LDS (<= 3 raw records = 96 B per lane, private to the lane: no barrier), and the
+// position bytes of 16 levels are fetched at once (4 VGPRs). ----
+template <bool LINES>
+__device__ __forceinline__ void merkle4_path_body(const int32_t* __restrict__ tab, const TagArg& tag,
+                                                  const Scalar32* __restrict__ leaves, const Scalar32* __restrict__ siblings,
+                                                  const uint8_t* __restrict__ positions, unsigned depth,
+                                                  Scalar32* __restrict__ roots, size_t n) {
+    __shared__ uint4 carry[LINES ? 6 : 1][LINES ? P252_BLOCK : 1];  // [half record][lane]: conflict-free 16-byte accesses
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (idx >= n) return;
     E29 cur = load_scalar(leaves + idx);
     const Scalar32* sib = siblings + idx * depth * 3;
     const uint8_t* pos = positions + idx * depth;
+    const unsigned t = threadIdx.x;
+    auto put = [&](int slot, const Raw32& r) {
+        carry[LINES ? 2 * slot : 0][LINES ? t : 0] = r.lo;
+        carry[LINES ? 2 * slot + 1 : 0][LINES ? t : 0] = r.hi;
+    };
+    auto get = [&](int slot) {
+        Raw32 r;
+        r.lo = carry[LINES ? 2 * slot : 0][LINES ? t : 0];
+        r.hi = carry[LINES ? 2 * slot + 1 : 0][LINES ? t : 0];
+        return r;
+    };
+    uint32_t pw[4] = {0u, 0u, 0u, 0u};  // LINES: the position bytes of levels 16 j .. 16 j + 15
 #pragma unroll 1
     for (unsigned l = 0; l < depth; ++l) {
-        const unsigned p = pos[l] & 3u;
+        unsigned p;
+        Raw32 ra, rb, rc;
+        if (LINES) {
+            if ((l & 15u) == 0) {  // (depth % 4 == 0 and the array is 4-byte aligned: whole words)
+                const uint32_t* pq = reinterpret_cast<const uint32_t*>(pos + l);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pw[k] = l + 4 * k < depth ? pq[k] : 0u;
+            }
+            const unsigned word = (l >> 2) & 3u, byte = l & 3u;  // wave-uniform
+            const uint32_t w = word == 0 ? pw[0] : word == 1 ? pw[1] : word == 2 ? pw[2] : pw[3];
+            p = (w >> (8 * byte)) & 3u;
+            const Scalar32* g = sib + (l & ~3u) * 3;  // the 3 lines (12 scalars) of this group of four levels
+            switch (l & 3u) {                         // wave-uniform
+                case 0: {  // line 0: the triple and the first scalar of the next one
+                    ra = load_raw(g + 0), rb = load_raw(g + 1), rc = load_raw(g + 2);
+                    put(0, load_raw(g + 3));
+                    break;
+                }
+                case 1: {  // line 1
+                    ra = get(0);
+                    rb = load_raw(g + 4), rc = load_raw(g + 5);
+                    const Raw32 x = load_raw(g + 6), y = load_raw(g + 7);
+                    put(0, x);
+                    put(1, y);
+                    break;
+                }
+                case 2: {  // line 2
+                    ra = get(0), rb = get(1);
+                    rc = load_raw(g + 8);
+                    const Raw32 x = load_raw(g + 9), y = load_raw(g + 10), z = load_raw(g + 11);
+                    put(0, x);
+                    put(1, y);
+                    put(2, z);
+                    break;
+                }
+                default: {  // nothing to fetch
+                    ra = get(0), rb = get(1), rc = get(2);
+                    break;
+                }
+            }
+        } else {
+            p = pos[l] & 3u;
+            ra = load_raw(sib + l * 3 + 0), rb = load_raw(sib + l * 3 + 1), rc = load_raw(sib + l * 3 + 2);
+        }
         E29 s[WIDTH];
 #pragma unroll
         for (int k = 0; k < NL; ++k) s[0].d[k] = tag.x0[k];
-        const E29 a = load_scalar(sib + l * 3 + 0), b = load_scalar(sib + l * 3 + 1), c = load_scalar(sib + l * 3 + 2);
+        const E29 a = raw_to_e29(ra), b = raw_to_e29(rb), c = raw_to_e29(rc);
         // children = siblings with `cur` inserted at slot p (per-lane select, no divergence)
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
@@ -633,6 +763,22 @@ __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path(con
         cur = s[1];
     }
     store_scalar(roots + idx, cur);
+}
+__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path(const int32_t* __restrict__ tab, TagArg tag,
+                                                             const Scalar32* __restrict__ leaves,
+                                                             const Scalar32* __restrict__ siblings,
+                                                             const uint8_t* __restrict__ positions,
+                                                             unsigned depth, Scalar32* __restrict__ roots,
+                                                             size_t n) {
+    merkle4_path_body<false>(tab, tag, leaves, siblings, positions, depth, roots, n);
+}
+__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_path_lines(const int32_t* __restrict__ tab, TagArg tag,
+                                                                   const Scalar32* __restrict__ leaves,
+                                                                   const Scalar32* __restrict__ siblings,
+                                                                   const uint8_t* __restrict__ positions,
+                                                                   unsigned depth, Scalar32* __restrict__ roots,
+                                                                   size_t n) {
+    merkle4_path_body<true>(tab, tag, leaves, siblings, positions, depth, roots, n);
 }
 
 // ---- shader-clock probe: a measurement aid for bench.py, not part of the hashing path.  ONE wave reads the shader-clock
@@ -684,6 +830,14 @@ static size_t coop_max_nodes() {
         return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)16384;
     }();
     return v;
+}
+// whole-cache-line fetches in the sponge and opening kernels (k_sponge_lines, k_merkle4_path_lines); P252_LINE_FETCH=0: off
+static bool line_fetch() {
+    static const bool on = [] {
+        const char* e = std::getenv("P252_LINE_FETCH");
+        return !(e && e[0] == '0');
+    }();
+    return on;
 }
 static inline bool coop8(size_t n) { return n <= coop_max_nodes() && n * 8 <= (size_t)65536; }
 
@@ -770,8 +924,13 @@ hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, 
                            static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_sponge, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
-                       static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+    // whole-line fetches when every message starts on a 64-byte boundary (P252_LINE_FETCH=0: never — A/B and tests)
+    if (line_fetch() && (in_len & 1u) == 0 && (reinterpret_cast<uintptr_t>(in) & 63u) == 0)
+        hipLaunchKernelGGL(k_sponge_lines, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+    else
+        hipLaunchKernelGGL(k_sponge, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
     return hipGetLastError();
 }
 
@@ -840,9 +999,16 @@ hipError_t launch_merkle4_path(const int32_t* tab, const TagArg& tag, const void
                            static_cast<const uint8_t*>(positions), depth, static_cast<Scalar32*>(roots), n);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_merkle4_path, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
-                       static_cast<const Scalar32*>(leaves), static_cast<const Scalar32*>(siblings),
-                       static_cast<const uint8_t*>(positions), depth, static_cast<Scalar32*>(roots), n);
+    // whole-line fetches when every lane's sibling path starts on a line boundary (depth x 96 B a multiple of 128 B)
+    if (line_fetch() && depth != 0 && (depth & 3u) == 0 && (reinterpret_cast<uintptr_t>(siblings) & 127u) == 0 &&
+        (reinterpret_cast<uintptr_t>(positions) & 3u) == 0)
+        hipLaunchKernelGGL(k_merkle4_path_lines, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(leaves), static_cast<const Scalar32*>(siblings),
+                           static_cast<const uint8_t*>(positions), depth, static_cast<Scalar32*>(roots), n);
+    else
+        hipLaunchKernelGGL(k_merkle4_path, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                           static_cast<const Scalar32*>(leaves), static_cast<const Scalar32*>(siblings),
+                           static_cast<const uint8_t*>(positions), depth, static_cast<Scalar32*>(roots), n);
     return hipGetLastError();
 }
 

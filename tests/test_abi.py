@@ -115,10 +115,10 @@ def test_abi_version_is_checked_by_the_binding():
     L.p252_abi_version.restype = ctypes.c_int
     assert L.p252_abi_version() == ver == _lib.ABI_VERSION
     assert _lib.lib().p252_abi_version() == ver  # (lib() would have raised ExtensionMissing on a mismatch)
-    # the staging-lane budget of the multi entry points: clamp(floor(cpus / n_ctx) - 1, 1, 3), no device needed
+    # the staging-lane budget of the multi entry points: clamp(floor(cpus / n_ctx), 1, 3), no device needed
     L.p252_staging_lanes.argtypes = [ctypes.c_size_t]
     import bench
     cpus = bench.usable_cpus()
     for n_ctx in (2, 4, 8, 64):
-        assert L.p252_staging_lanes(n_ctx) == max(1, min(3, cpus // n_ctx - 1)), n_ctx
+        assert L.p252_staging_lanes(n_ctx) == max(1, min(3, cpus // n_ctx)), n_ctx
     assert L.p252_staging_lanes(1) == L.p252_staging_lanes(0) == (2 if cpus < 4 else 3)
