@@ -526,6 +526,10 @@ def roofline_of(W, launch_ms, clk_before, clk_after, sclk_sysfs=None):
     hbm_gbps = per_gpu_rate * BYTES_PER_PERM[wl] / 1e9
     kern = KERNEL_OF[wl]
     lanes_per_perm, isa_key, pmc_key = 1, None, None
+    if wl in ("sponge42", "openings") and os.environ.get("P252_LINE_FETCH", "1")[:1] != "0":
+        # 42-scalar messages / depth-12 paths in line-aligned arrays: the whole-line-fetch builds (kernels.hip); the counter
+        # passes and ISA counts are filed under the base name
+        isa_key, pmc_key, kern = None, kern, kern + "_lines"
     coop_max = int(os.environ.get("P252_COOP_MAX_NODES", "16384"))
     items = n  # independent states per launch (digests, messages, openings)
     if wl == "merkle4_digests" and 8192 < items <= min(coop_max, 16384):

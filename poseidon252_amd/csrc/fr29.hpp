@@ -230,16 +230,19 @@ struct RK {
     int64_t bias;   // 2^31, a VGPR pair: the addend of the first multiply-add of every column that gets a wide step
     int32_t eight;  // 8, an SGPR the optimiser cannot see through (so that x8 stays a multiply-add, not shift + add)
     int32_t eight_p1;  // -p'_1 = 8 again, a second opaque copy: with one, h*8 + q*8 is refactored into a 64-bit (h+q)*8
+    int32_t neg1;      // -1 = -p'_0 for fold_top: column 0 -= q as ONE multiply-add instead of a two-instruction 64-bit subtract
 };
 P252_HD RK make_rk() {
     RK k;
     k.bias = (int64_t)1 << 31;
     k.eight = 8;
     k.eight_p1 = 8;
+    k.neg1 = -1;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("" : "+v"(k.bias));
     asm("; carry x8" : "+s"(k.eight));  // (distinct strings: identical asm statements would be merged)
     asm("; -p'_1" : "+s"(k.eight_p1));
+    asm("; -p'_0" : "+s"(k.neg1));
 #endif
     return k;
 }
@@ -299,6 +302,45 @@ P252_HD E29 redc_w(A29& t, const RK& K) {
     }
     P252_TRK_COL(t.c[2 * NL - 1] + carry);
     r.d[NL - 1] = opaque_digit((int32_t)(t.c[2 * NL - 1] + carry));
+    P252_TRK_TOP(r.d[NL - 1]);
+    return r;
+}
+
+// ---- reduction from the TOP (the integer recurrence of the partial rounds, hades29.hpp::ai_recur) ----
+// V = sum c[k] 2^(29 k), nine signed columns, |V| < 2^283 (a sum of nine one-digit multiples of lazy residues).  Instead of
+// dividing low digits away (Montgomery steps: 9 multiply-adds per digit, and the value changes scale by 2^-29 each) a
+// multiple of p is subtracted that the TOP of the value determines: q = floor(V / 2^252) * M >> 32 with
+// M = round(2^284 / p) — the top two columns give V / 2^232 to within 3 units of 2^50, one v_mul_hi_i32 turns that into the
+// quotient to within 1.6 — and V - q p is a lazy residue below 1.2 p (|q| < 2^28; simulated over adversarial inputs in
+// tests/test_host_arith.py).  Cost: 4 instructions for q, 9 multiply-adds for q p (balanced digits of p, as in the wide
+// step), the 8-digit carry chain; the value keeps its scale, so terms of every age enter the recurrence ALIGNED.
+#define P252_FOLD_SHIFT 20
+#define P252_FOLD_M 592775503 /* round(2^284 / p) */
+P252_HD E29 fold_top(int64_t c[NL], const RK& K) {
+    P252_TRK_COL(c[NL - 1]);
+    const int64_t t = c[NL - 1] + (c[NL - 2] >> WB);
+    const int32_t th = opaque_digit((int32_t)(t >> P252_FOLD_SHIFT));
+    const int64_t q = opaque_digit((int32_t)(((int64_t)th * (int64_t)P252_FOLD_M) >> 32));
+    c[0] += q * (int64_t)K.neg1;
+    c[1] += q * (int64_t)K.eight; /* p'_1 = -8 */
+    c[2] -= q * (int64_t)P252_PB_2;
+    c[3] -= q * (int64_t)P252_PB_3;
+    c[4] -= q * (int64_t)P252_PB_4;
+    c[5] -= q * (int64_t)P252_PB_5;
+    c[6] -= q * (int64_t)P252_PB_6;
+    c[7] -= q * (int64_t)P252_PB_7;
+    c[8] -= q * (int64_t)P252_PB_8;
+    E29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) {
+        const int64_t v = c[k] + carry;
+        P252_TRK_COL(c[k]);
+        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
+        carry = v >> WB;
+    }
+    P252_TRK_COL(c[NL - 1] + carry);
+    r.d[NL - 1] = opaque_digit((int32_t)(c[NL - 1] + carry));
     P252_TRK_TOP(r.d[NL - 1]);
     return r;
 }

@@ -142,48 +142,32 @@ P252_HD void hades_permute_int(E29 s[WIDTH], TP tab) {
 // History of the partial phase: rings of HIST entries, U_q at Us[q mod HIST] and W_q at Ws[q mod HIST]; with
 // HIST rounds per loop iteration every ring position is a compile-time constant and nothing is ever moved.
 // One step (q = index of the partial round, 1..60):  W_q = sbox(U_q) * G_q / R';
-//   U_{q+1} = ( sum_m A_m U_{q+1-m} 2^(29(5-m)) + sum_n B_n W_{q-n} 2^(29(4-n)) ) / 2^145 + K_{q+1}
-// A term of age j sits j digits lower, so the nine one-digit products land in columns 0..12, five Montgomery
-// digit steps clear columns 0..4, and K (nine digits) is simply preloaded into columns 5..13.
+//   U_{q+1} = sum_m A_m U_{q+1-m} + sum_n B_n W_{q-n} + K_{q+1}   (mod p: fold_top)
+// The stored values carry the geometric scale sigma_{q+1} = sigma_q D / R (tables.hpp), for which ALL nine coefficients
+// are one-digit integers at the same weight: nine one-digit products into nine columns that start as K's digits, then
+// the reduction from the top (fr29.hpp fold_top: 13 instructions + the carry chain).  Round 2's recurrence divided by 2^29
+// per round of age instead (terms of age j one digit lower, five Montgomery digit steps = 50 instructions).
 // ab = A_1..A_4, B_0..B_4 (ints); kg = K_{q+1}[9], G_q[9].  U_{q+1} overwrites U_{q-4}, W_q overwrites W_{q-5}.
 constexpr int HIST = 5;
 template <int QM /* q mod HIST */, class TP>
 P252_HD void ai_recur(E29 Us[HIST], const E29 Ws[HIST], TP ab, TP kg, const RK& K) {  // U_{q+1} from the rings (W_q included)
     constexpr int Q = QM + HIST;  // keeps (Q - j) % HIST non-negative
-    int64_t c[NL + 5];
+    int64_t c[NL];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) c[k] = K.bias;  // the five columns that get a (wide) digit step, fr29.hpp
+    for (int k = 0; k < NL; ++k) c[k] = kg[k];
 #pragma unroll
-    for (int k = 0; k < NL; ++k) c[5 + k] = kg[k];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {  // base column 4 - j: A_{j+1} U_{q-j} and B_j W_{q-j}
+    for (int j = 0; j < 4; ++j) {  // A_{j+1} U_{q-j} and B_j W_{q-j}
         const int64_t aj = ab[j], bj = ab[4 + j];
 #pragma unroll
         for (int k = 0; k < NL; ++k)
-            c[4 - j + k] += (int64_t)Us[(Q - j) % HIST].d[k] * aj + (int64_t)Ws[(Q - j) % HIST].d[k] * bj;
+            c[k] += (int64_t)Us[(Q - j) % HIST].d[k] * aj + (int64_t)Ws[(Q - j) % HIST].d[k] * bj;
     }
     {
         const int64_t b4 = ab[8];
 #pragma unroll
         for (int k = 0; k < NL; ++k) c[k] += (int64_t)Ws[(Q - 4) % HIST].d[k] * b4;
     }
-    P252_WSTEP(c, 0, NL + 5, K)
-    P252_WSTEP(c, 1, NL + 5, K)
-    P252_WSTEP(c, 2, NL + 5, K)
-    P252_WSTEP(c, 3, NL + 5, K)
-    P252_WSTEP(c, 4, NL + 5, K)
-    E29 r;
-    int64_t carry = 0;
-#pragma unroll
-    for (int k = 0; k < NL - 1; ++k) {
-        const int64_t v = c[5 + k] + carry;
-        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
-        carry = v >> WB;
-    }
-    P252_TRK_COL(c[NL + 4] + carry);
-    r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 4] + carry));
-    P252_TRK_TOP(r.d[NL - 1]);
-    Us[(Q + 1) % HIST] = r;
+    Us[(Q + 1) % HIST] = fold_top(c, K);
 }
 template <int QM /* q mod HIST */, class TP>
 P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, const RK& K) {
@@ -192,42 +176,36 @@ P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, const RK& K) {
 }
 
 // Exit row i: lanes 0..3 of the state after round 60 from (U_58..U_61, W_57..W_60).  The coefficients are rationals
-// with a common denominator per row: eight two-digit integer products (term r of the U's at base column r + 1,
-// term t of the W's at base column t: one digit lower per round of age, as in ai_round), six Montgomery digit steps,
-// then ONE generic product by fix_i = 2^58 R' / den_i; add_i rides in the high columns.
+// with a common denominator per row: eight two-digit integer products, all at the same weight (the history's scale is
+// geometric with the very ratio the coefficients' denominators have), two Montgomery digit steps, then ONE generic product
+// by fix_i = 2^58 R' / den_i; add_i rides in the high columns.
 // n = 8 x (lo, hi) digits: U_58..U_61 then W_57..W_60.
 template <class TP>
 P252_HD E29 exit_row(const E29* const u[4], const E29* const w[4], TP n, TP fix, TP add, const RK& K) {
-    int64_t c[NL + 6];
+    int64_t c[NL + 2];
 #pragma unroll
-    for (int k = 0; k < NL + 6; ++k) c[k] = k < 6 ? K.bias : 0;
+    for (int k = 0; k < NL + 2; ++k) c[k] = k < 2 ? K.bias : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t ylo = n[2 * r], yhi = n[2 * r + 1], vlo = n[8 + 2 * r], vhi = n[8 + 2 * r + 1];
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-            c[r + 1 + k] += (int64_t)u[r]->d[k] * ylo;
-            c[r + 2 + k] += (int64_t)u[r]->d[k] * yhi;
-            c[r + k] += (int64_t)w[r]->d[k] * vlo;
-            c[r + 1 + k] += (int64_t)w[r]->d[k] * vhi;
+            c[k] += (int64_t)u[r]->d[k] * ylo + (int64_t)w[r]->d[k] * vlo;
+            c[k + 1] += (int64_t)u[r]->d[k] * yhi + (int64_t)w[r]->d[k] * vhi;
         }
     }
-    P252_WSTEP(c, 0, NL + 6, K)
-    P252_WSTEP(c, 1, NL + 6, K)
-    P252_WSTEP(c, 2, NL + 6, K)
-    P252_WSTEP(c, 3, NL + 6, K)
-    P252_WSTEP(c, 4, NL + 6, K)
-    P252_WSTEP(c, 5, NL + 6, K)
+    P252_WSTEP(c, 0, NL + 2, K)
+    P252_WSTEP(c, 1, NL + 2, K)
     E29 r;
     int64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < NL - 1; ++k) {
-        const int64_t v = c[6 + k] + carry;
+        const int64_t v = c[2 + k] + carry;
         r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
         carry = v >> WB;
     }
-    P252_TRK_COL(c[NL + 5] + carry);
-    r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 5] + carry));
+    P252_TRK_COL(c[NL + 1] + carry);
+    r.d[NL - 1] = opaque_digit((int32_t)(c[NL + 1] + carry));
     P252_TRK_TOP(r.d[NL - 1]);
     A29 t;
     acc_set_hi_c_w(t, add, K);
@@ -271,23 +249,15 @@ P252_HD E29 entry_row(const E29 x[WIDTH], TP n, TP fix, TP add, const RK& K) {
     return redc_w(t, K);
 }
 
-// x * m + add for a small integer m (W_0 = 28 X_4 + const): nine products and a carry chain, no reduction —
-// the result is a 9-digit value below 2^260, used only as a multiplicand of one-digit products.
+// x * m + add for a small integer m (W_0 = 28 X_4 + const): nine products, then the reduction from the top — the result is
+// an ordinary lazy residue (below 1.2 p), which the aligned recurrence's quotient estimate assumes of every term.
 template <class TP>
-P252_HD E29 small_mul_add(const E29& x, int32_t m, TP add) {
-    E29 r;
-    int64_t carry = 0;
+P252_HD E29 small_mul_add(const E29& x, int32_t m, TP add, const RK& K) {
+    int64_t c[NL];
     const int64_t mm = m;
 #pragma unroll
-    for (int k = 0; k < NL - 1; ++k) {
-        const int64_t v = (int64_t)x.d[k] * mm + (int64_t)add[k] + carry;
-        r.d[k] = opaque_digit((int32_t)((uint32_t)v & DMASK));
-        carry = v >> WB;
-    }
-    P252_TRK_COL((int64_t)x.d[NL - 1] * mm + (int64_t)add[NL - 1] + carry);
-    r.d[NL - 1] = opaque_digit((int32_t)((int64_t)x.d[NL - 1] * mm + (int64_t)add[NL - 1] + carry));
-    P252_TRK_TOP1(r.d[NL - 1]);
-    return r;
+    for (int k = 0; k < NL; ++k) c[k] = (int64_t)x.d[k] * mm + (int64_t)add[k];
+    return fold_top(c, K);
 }
 
 // The entry of the partial phase from the five S-box outputs x of full round 3: U_1 (the integer row of lane 4) and the
@@ -296,7 +266,18 @@ template <class TP>
 P252_HD void arma_entry(const E29 x[WIDTH], E29 Us[HIST], E29 Ws[HIST], TP tab, const RK& K) {
     typedef Tab29Layout Lay;
     constexpr int RF = FULL_ROUNDS / 2;
-    Us[1] = int_row(x, tab + Lay::INT_N + 4, tab + Lay::AI_KAPPA + ((RF - 1) * WIDTH + 4) * NL);  // U_1
+    {  // U_1: lane 4's integer row of full round 3, reduced from the top instead of by a digit step (scale e L / R)
+        int64_t c[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) c[k] = (tab + Lay::AI_KAPPA + ((RF - 1) * WIDTH + 4) * NL)[k];
+#pragma unroll
+        for (int j = 0; j < WIDTH; ++j) {
+            const int64_t nj = (tab + Lay::INT_N + 4)[j];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) c[k] += (int64_t)x[j].d[k] * nj;
+        }
+        Us[1] = fold_top(c, K);
+    }
     sched_fence();
     // U_0, U_-1, U_-2: virtual
     Us[0] = entry_row<1>(x, tab + Lay::AI_ENT_N, tab + Lay::AI_ENT_FIX, tab + Lay::AI_ENT_ADD, K);
@@ -307,7 +288,7 @@ P252_HD void arma_entry(const E29 x[WIDTH], E29 Us[HIST], E29 Ws[HIST], TP tab, 
     sched_fence();
     Us[2] = e29_zero();  // (free slot)
     // W_0: virtual, = the lane-4 S-box output at the W scale (28 = 13 D / K); W_-1, W_-2, W_-3 = 0
-    Ws[0] = small_mul_add(x[4], ENTRY_W0_INT, tab + Lay::AI_ENT_ADD + 3 * NL);
+    Ws[0] = small_mul_add(x[4], ENTRY_W0_INT, tab + Lay::AI_ENT_ADD + 3 * NL, K);
 #pragma unroll
     for (int i = 1; i < HIST; ++i) Ws[i] = e29_zero();
 }

@@ -384,11 +384,14 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path_coop(const int32_t*
 // caches: 1.19 x the algorithmic traffic (profiles/r02_pmc_k_sponge.txt).  LINES = true: every lane fetches WHOLE LINES —
 // a lane whose message starts sh = 2 scalars into a line reads scalars 4 it + 2 .. 4 it + 5 at block it, absorbs the two
 // carried over from the previous fetch plus the first two of this one and carries the other two (16 VGPRs, raw) across the
-// permutation.  Every line is touched once (the half lines at a message's ends excepted).  Taken when in_len is even and
-// the array is 64-byte aligned (kernel-uniform); otherwise block by block as before. ----
+// permutation.  A message that ENDS in mid-line shares that line with the head of the next lane's message, which fetches it
+// at its first block: the lane fetches its two tail scalars then as well (the same line at the same time: one HBM fetch)
+// and parks them in LDS (64 B per lane, private: no barrier) until its last block.  Every line is touched once.  Taken
+// when in_len is even and the array is 64-byte aligned (kernel-uniform); otherwise block by block as before. ----
 template <bool LINES>
 __device__ __forceinline__ void sponge_body(const int32_t* __restrict__ tab, const TagArg& tag, const Scalar32* __restrict__ in,
                                             unsigned in_len, unsigned out_len, Scalar32* __restrict__ out, size_t n) {
+    __shared__ uint4 tail[LINES ? 4 : 1][LINES ? P252_BLOCK : 1];  // [half record][lane]: the two tail scalars of a message ending in mid-line
     const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (idx >= n) return;
     const Scalar32* my_in = in + idx * in_len;
@@ -402,10 +405,19 @@ __device__ __forceinline__ void sponge_body(const int32_t* __restrict__ tab, con
     // my message starts `sh` scalars into its 128-byte line: 0, or 2 for every other message of an even in_len
     const unsigned sh = LINES ? (unsigned)((reinterpret_cast<uintptr_t>(my_in) >> 5) & 3u) : 0u;
     const bool shifted = sh != 0;
+    const bool tail_half = LINES && ((sh + in_len) & 3u) == 2u && in_len >= 2;  // my message ends two scalars into a line
+    const unsigned tl = LINES ? threadIdx.x : 0u;
     Raw32 c0 = raw_zero(), c1 = raw_zero();
     if (LINES) {  // the half line at the head of a shifted message (unshifted lanes: the same line block 0 fetches next)
         if (0 < in_len) c0 = load_raw(my_in);
         if (1 < in_len) c1 = load_raw(my_in + 1);
+        if (tail_half) {  // (the next lane fetches this very line now, as the head of its message)
+            const Raw32 t0 = load_raw(my_in + in_len - 2), t1 = load_raw(my_in + in_len - 1);
+            tail[0][tl] = t0.lo;
+            tail[1][tl] = t0.hi;
+            tail[2][tl] = t1.lo;
+            tail[3][tl] = t1.hi;
+        }
     }
 #pragma unroll 1
     for (unsigned it = 0; it < absorb_blocks + squeeze_blocks; ++it) {
@@ -413,10 +425,18 @@ __device__ __forceinline__ void sponge_body(const int32_t* __restrict__ tab, con
         if (it < absorb_blocks) {
             if (LINES) {
                 Raw32 L[4];
+                // the line this fetch addresses reaches past the end of my message: what is mine of it are the two tail scalars
+                const bool parked = tail_half && it * 4 + sh + 4 > in_len;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned pos = it * 4 + sh + j;
-                    L[j] = pos < in_len ? load_raw(my_in + pos) : raw_zero();
+                    L[j] = (pos < in_len && !parked) ? load_raw(my_in + pos) : raw_zero();
+                }
+                if (parked) {
+                    L[0].lo = tail[0][tl];
+                    L[0].hi = tail[1][tl];
+                    L[1].lo = tail[2][tl];
+                    L[1].hi = tail[3][tl];
                 }
                 const Raw32 e[4] = {raw_select(shifted, c0, L[0]), raw_select(shifted, c1, L[1]), raw_select(shifted, L[0], L[2]),
                                     raw_select(shifted, L[1], L[3])};

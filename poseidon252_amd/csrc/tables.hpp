@@ -319,10 +319,11 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
 
     // ================= (C) integer ARMA =================
     // a_m = R^m a~_m and beta_n = R^(n+1) b~_n with A_m = a~_m D^m, B_n = b~_n D^n K one-digit integers.
-    // Stored U_q = sigma_q u_q with sigma_{q+1} = sigma_q mu, mu = D / (R 2^29); W_q = (sigma_q D / K) v_q =
+    // Stored U_q = sigma_q u_q with sigma_{q+1} = sigma_q mu, mu = D / R; W_q = (sigma_q D / K) v_q =
     // sbox(U_q) * G_q / R' with G_q = R'^5 D / (K sigma_q^4).  Then (hades29.hpp::ai_round)
-    //   U_{q+1} = ( sum_m A_m U_{q+1-m} 2^(29(5-m)) + sum_n B_n W_{q-n} 2^(29(4-n)) ) / 2^145 + K_{q+1},
-    //   K_{q+1} = sigma_{q+1} kappa_{q+1}.
+    //   U_{q+1} = sum_m A_m U_{q+1-m} + sum_n B_n W_{q-n} + K_{q+1}  (mod p, reduced from the top: fr29.hpp fold_top),
+    //   K_{q+1} = sigma_{q+1} kappa_{q+1}
+    // — every term at the same weight.  (Round 2 used mu = D / (R 2^29): a Montgomery digit step per round of age.)
     // All additive constants come from the zero-input trajectory of the affine system (they are
     // trajectory-independent).  Entry: (u_0, u_-1, u_-2, v_0) = H y_1 + h_0 (y_1 = state entering the first
     // partial round) is the virtual history for which the recurrence already holds at q = 1..4 with
@@ -405,14 +406,14 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
             for (int i = 0; i < 4; ++i) H[i][j] = col[i];
         }
         // ---- scales ----
-        const FrHost mu = Df * RM.inv() * T29.inv();
+        const FrHost mu = Df * RM.inv();
         const FrHost mu_inv = mu.inv();
         FrHost s = RM, sigma1 = FrHost::one(), e3 = FrHost::one();
         for (int k = 0; k < RF; ++k) {
             const FrHost e = s.pow5() * RP4inv;
             const FrHost sn = e * step;
             for (int i = 0; i < WIDTH; ++i) T.ai_kappa[k][i] = (k < RF - 1 || i == 4) ? T29 * sn * C[k + 1][i] : FrHost::zero();
-            if (k == RF - 1) sigma1 = sn, e3 = e;
+            if (k == RF - 1) sigma1 = sn * T29, e3 = e;  // U_1 = the integer row of lane 4 WITHOUT its digit step (arma_entry): e L / R
             s = sn;
         }
         FrHost sig[PARTIAL_ROUNDS + 5];  // sig[q + 2] = sigma_q for q = -2..61
@@ -453,7 +454,7 @@ inline void derive_tables(const unsigned char* arc_bin, const unsigned char* mds
             T.ai_k[q - 1] = sig[q + 1 + 2] * kappa[q + 1];
         }
         // exit rows in integer form (hades29.hpp::exit_row):
-        //   Z_i = ( sum_r ny_ir U_{58+r} 2^(29(r+1)) + sum_t nv_it W_{57+t} 2^(29 t) ) / 2^174 * fix_i / R' + add_i
+        //   Z_i = ( sum_r ny_ir U_{58+r} + sum_t nv_it W_{57+t} ) / 2^58 * fix_i / R' + add_i
         s = sig[PARTIAL_ROUNDS + 1 + 2];
         for (int i = 0; i < 4; ++i) {
             const FrHost den = FrHost::from_u64((uint64_t)EXIT_DEN_INT[i]);
@@ -661,10 +662,10 @@ inline double max_column_bound29(const int32_t* tab) {
             if (erow > worst) worst = erow;
         }
         group({Lay::AI_EX_FIX + i * NL});
-        // integer exit row: a column collects at most one digit product per coefficient digit (16 of them), then six digit steps
+        // integer exit row: a column collects at most one digit product per coefficient digit (16 of them), then two digit steps
         double nsum = 0;
         for (int t = 0; t < 16; ++t) nsum += absd(tab[Lay::AI_EX_N + i * 2 * NL + t]);
-        const double row = DIG * nsum + 6.0 * WSTEP + 68719476736.0;
+        const double row = DIG * nsum + 2.0 * WSTEP + 68719476736.0;
         if (row > worst) worst = row;
     }
     {  // integer rows: five one-digit terms (row 0 has the largest sum) of possibly un-carried lanes + kappa + one digit step
@@ -673,10 +674,11 @@ inline double max_column_bound29(const int32_t* tab) {
         const double row = LAZY * nsum + 268435456.0 + DIG * (double)P252_P29_1 + 68719476736.0;
         if (row > worst) worst = row;
     }
-    {  // integer ARMA row: a column collects at most one digit of each of the nine terms, then five digit steps
+    {  // integer ARMA row: a column collects one digit of each of the nine terms (all at the same weight) and K's digit, then
+        // the quotient of the reduction from the top (|q| < 2^29) times one balanced digit of p
         double asum = 0;
         for (int t = 0; t < NL; ++t) asum += absd(tab[Lay::AI_AB + t]);
-        const double row = 2.0 * DIG * asum /* W_0 = 28 X_4: top digit up to 2^30 */ + 5.0 * WSTEP + 268435456.0 + 68719476736.0;
+        const double row = DIG * asum + 536870912.0 * ab(P252_PB_5) + DIG + 68719476736.0;
         if (row > worst) worst = row;
     }
     // S-box: element x element (9 products of 2^29 x 2^29) and squarings (<= 4.5 * 2^59)

@@ -516,8 +516,8 @@ def derive_armaint(C, M):
         if k < Rf - 1:
             out["fr_kappa"][k] = [pow(2, 29, P) * s_next % P * C[k + 1][i] % P for i in range(5)]
         else:
-            sigma1 = s_next
-            mu = D_INT * inv(RM) % P * i29 % P
+            sigma1 = s_next * pow(2, 29, P) % P   # U_1 = lane 4's integer row WITHOUT its digit step: scale e L / R
+            mu = D_INT * inv(RM) % P              # every term of the recurrence at the same weight (round 2: D / (R 2^29))
             sig = lambda q: sigma1 * pow(mu, q - 1, P) % P          # also for q <= 0
             omg = lambda q: sig(q) * D_INT % P * inv(K_INT) % P
             # theta_i = sum_j (H M)_ij v_j + (H C_4 + h0)_i with v_j = X_j / e
@@ -542,11 +542,11 @@ def derive_armaint(C, M):
         out["G"][q] = pow(RP, 5, P) * D_INT % P * inv(K_INT) % P * inv(pow(sig(q), 4, P)) % P
         out["K"][q + 1] = sig(q + 1) * kappa[q + 1] % P
     s = sig(61)
-    # exit rows in integer form: Z_i = ( sum_r ny U_{58+r} 2^(29(r+1)) + sum_t nv W_{57+t} 2^(29 t) ) / 2^174 * fix_i / R' + add_i
+    # exit rows in integer form: Z_i = ( sum_r ny U_{58+r} + sum_t nv W_{57+t} ) / 2^58 * fix_i / R' + add_i
     for i in range(4):
         den, ny, nv = EXIT_INT[i]
-        assert all(s * Gy[i][r] % P * inv(sig(58 + r)) % P == ny[r] * inv(den) % P * pow(i29, 3 - r, P) % P for r in range(4))
-        assert all(s * Gv[i][t] % P * inv(omg(57 + t)) % P == nv[t] * inv(den) % P * pow(i29, 4 - t, P) % P for t in range(4))
+        assert all(s * Gy[i][r] % P * inv(sig(58 + r)) % P == ny[r] * inv(den) % P for r in range(4))
+        assert all(s * Gv[i][t] % P * inv(omg(57 + t)) % P == nv[t] * inv(den) % P for t in range(4))
     out["ex_fix"] = [pow(2, 58, P) * inv(EXIT_INT[i][0]) % P * RP % P for i in range(4)]
     out["ex_add"] = [s * exit_add[i] % P for i in range(4)]
     for k in range(Rf + PARTIAL, ROUNDS):
@@ -580,19 +580,18 @@ def perm_armaint(x_mont, C=None, M=None, T=None):
         acc = sum(ENTRY_INT[i][j] * X[j] for j in range(5)) * pow(i29, steps, P) % P
         th.append(grow([(acc, T["ent_fix"][i])], T["ent_add"][i]))
     th.append((28 * X[4] + T["ent_add"][3]) % P)
-    U = {1: irow(X, 4, T["fr_kappa"][Rf - 1][4]), 0: th[0], -1: th[1], -2: th[2]}
+    U = {1: (sum(N_INT[4][j] * X[j] for j in range(5)) + T["fr_kappa"][Rf - 1][4]) % P, 0: th[0], -1: th[1], -2: th[2]}
     W = {0: th[3], -1: 0, -2: 0, -3: 0}
-    i145 = pow(i29, 5, P)
     for q in range(1, PARTIAL + 1):
         W[q] = mm(sbox(U[q]), T["G"][q])
-        acc = sum(A_INT[m - 1] * U[q + 1 - m] << (29 * (5 - m)) for m in range(1, 5)) + sum(B_INT[n] * W[q - n] << (29 * (4 - n)) for n in range(5))
-        U[q + 1] = (acc * i145 + T["K"][q + 1]) % P
-    i174 = pow(i29, 6, P)
+        acc = sum(A_INT[m - 1] * U[q + 1 - m] for m in range(1, 5)) + sum(B_INT[n] * W[q - n] for n in range(5))
+        U[q + 1] = (acc + T["K"][q + 1]) % P
+    i58 = pow(i29, 2, P)
     Z = []
     for i in range(4):
         _, ny, nv = EXIT_INT[i]
-        acc = sum(ny[r] * U[58 + r] << (29 * (r + 1)) for r in range(4)) + sum(nv[t] * W[57 + t] << (29 * t) for t in range(4))
-        Z.append(grow([(acc * i174 % P, T["ex_fix"][i])], T["ex_add"][i]))
+        acc = sum(ny[r] * U[58 + r] for r in range(4)) + sum(nv[t] * W[57 + t] for t in range(4))
+        Z.append(grow([(acc * i58 % P, T["ex_fix"][i])], T["ex_add"][i]))
     Z.append(U[61])
     for k in range(Rf + PARTIAL, ROUNDS):
         X = [sbox(z) for z in Z]

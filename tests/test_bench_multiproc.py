@@ -62,7 +62,7 @@ def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
     (configs[2]; configs[4] at 8 ranks) and the 42 -> 5 sponge (configs[3]) under "secondary", each with its own
     self-consistency check, roofline, measured clock and (N = 1) oracle check of a sample.  Scaled down here."""
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "15",
-                                   "--secondary-log2n", "13"], cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
+                                   "--secondary-log2n", "14"], cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
     d = _one_json_line(out)
     for k in REQUIRED:
         assert k in d, k
@@ -70,15 +70,15 @@ def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
     sec = d["secondary"]
     assert sorted(sec) == ["sponge42", "tree"]
     t, s = sec["tree"], sec["sponge42"]
-    assert "2^17-leaf arity-4 Merkle tree" in t["workload"]
-    assert t["units_per_gpu_per_step"] == 43691  # 2^17 leaves: 32768 + 8192 + ... + 8 + 2 + 1 nodes
-    assert s["units_per_gpu_per_step"] == 12 << 13 and "42 scalars -> 5 outputs" in s["workload"]
+    assert "2^18-leaf arity-4 Merkle tree" in t["workload"]
+    assert t["units_per_gpu_per_step"] == (4 ** 9 - 1) // 3  # 4^9 leaves: 65536 + 16384 + ... + 4 + 1 = 87381 nodes
+    assert s["units_per_gpu_per_step"] == 12 << 14 and "42 scalars -> 5 outputs" in s["workload"]
     for w in (t, s):
         assert w["self_consistency_ok"] is True and w["parity_sample_ok"] is True and w["n_gpus"] == 1 and w["ranks"] == 1
         assert w["value"] == pytest.approx(w["units_per_gpu_per_step"] * w["steps"] / (w["ms_per_step"] * w["steps"] * 1e-3), rel=1e-6)
         assert w["steps"] == 3 and w["roofline"]["executed"]["frac"] > 0 and w["roofline"]["launch_ms_mean"] > 0
         _check_clock(w["roofline"])
-    assert t["roofline"]["kernel"] == "k_merkle4" and s["roofline"]["kernel"] == "k_sponge"
+    assert t["roofline"]["kernel"] == "k_merkle4" and s["roofline"]["kernel"] == "k_sponge_lines"
     cb = d["cpu_baseline"]
     assert cb["parity_samples"] == {"merkle4_digests": True, "tree": True, "sponge42": True} and cb["parity_sample_ok"] is True
     assert cb["threads"] == cb["cores"] >= 1 and "cpu_quota" in cb and cb["cpus_visible"] >= 1
@@ -95,7 +95,7 @@ def test_bench_cpu_baseline_leg_checks_gpu_sample(gpu_ctx):
     assert d["self_consistency_ok"] is True
 
 
-@pytest.mark.parametrize("workload,log2n,kernel", [("sponge42", "14", "k_sponge"), ("openings", "14", "k_merkle4_path"), ("tree", "14", "k_merkle4"),
+@pytest.mark.parametrize("workload,log2n,kernel", [("sponge42", "14", "k_sponge_lines"), ("openings", "14", "k_merkle4_path_lines"), ("tree", "14", "k_merkle4"),
                                                    ("encrypt", "14", "k_crypt"),
                                                    # batches of <= 8,192 items run (and are priced as) the lane-group kernels
                                                    ("sponge42", "12", "k_sponge_coop"), ("openings", "11", "k_merkle4_path_coop"),

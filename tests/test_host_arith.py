@@ -1,6 +1,7 @@
 """The DEVICE arithmetic (poseidon252_amd/csrc/fr29.hpp, hades29.hpp, tables.hpp) compiled for the
 host and checked limb-for-limb against the oracle.  Same source the kernels run; no GPU needed."""
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -9,6 +10,7 @@ import pytest
 import pymodel
 
 P = pymodel.P
+HERE = os.path.dirname(os.path.abspath(__file__))
 u64p = ctypes.POINTER(ctypes.c_uint64)
 
 
@@ -213,7 +215,8 @@ def test_dynamic_bounds(oracle_mod, hosttest_lib):
     """Instrumented host build of the kernels' schedule: the largest |column| any reduction meets and the largest
     |top digit| any reduction produces, over random, edge and adversarial (non-canonical, digit-saturating) states,
     stay inside what the static analysis (max_column_bound29) assumes: columns < 2^63, top digits < 2^27 (the
-    wide Montgomery step lets values drift to several p; W_0 = 28 X_4 is the largest: below 2^31 as an int32 digit)."""
+    wide Montgomery step lets values drift to several p; W_0 = 28 X_4 is reduced from the top like every term of the
+    aligned recurrence since round 3, so no value is special any more)."""
     import math
     for f in (hosttest_lib.ht_bounds_max_col, hosttest_lib.ht_bounds_max_top, hosttest_lib.ht_bounds_max_top1):
         f.restype = ctypes.c_double
@@ -231,8 +234,53 @@ def test_dynamic_bounds(oracle_mod, hosttest_lib):
     col, top, top1 = hosttest_lib.ht_bounds_max_col(), hosttest_lib.ht_bounds_max_top(), hosttest_lib.ht_bounds_max_top1()
     assert 2 ** 58 < col < 2 ** 62.6, math.log2(col)
     assert top < 2 ** 27, math.log2(top)     # what max_column_bound29 assumes for the multiplicands of generic products
-    assert top1 < 2 ** 30, math.log2(top1)   # W_0 = 28 X_4: enters one-digit products only (charged as 2 x 2^29 there)
-    print("max |column| 2^%.2f, max |top digit| 2^%.2f (W_0: 2^%.2f)" % (math.log2(col), math.log2(top), math.log2(top1)))
+    assert top1 == 0  # (round 2 tracked W_0 = 28 X_4 apart: up to 2^30; it is an ordinary lazy residue now)
+    print("max |column| 2^%.2f, max |top digit| 2^%.2f" % (math.log2(col), math.log2(top)))
+
+
+def test_fold_top_quotient_bounds():
+    """fr29.hpp fold_top (the aligned recurrence's reduction from the top) in big ints: for nine one-digit multiples of
+    lazy residues up to 5.3 p — signs chosen adversarially for the actual coefficients — the shifted top of the value fits
+    the int32 the quotient estimate multiplies, the quotient stays below 2^29, every column below 2^62, and what is left
+    is below 1.3 p.  The constants are the header's."""
+    import re
+    src = open(os.path.join(os.path.dirname(HERE), "poseidon252_amd", "csrc", "fr29.hpp")).read()
+    M = int(re.search(r"#define P252_FOLD_M (\d+)", src).group(1))
+    SH = int(re.search(r"#define P252_FOLD_SHIFT (\d+)", src).group(1))
+    assert M == round(2 ** (232 + SH + 32) / P)
+    pb = [1] + [int(re.search(r"#define P252_PB_%d \((-?\d+)\)" % k, src).group(1)) for k in range(1, 9)]
+    assert sum(d << (29 * k) for k, d in enumerate(pb)) == P
+    coef = pymodel.A_INT + pymodel.B_INT
+
+    def digits(v):
+        d = []
+        for _ in range(8):
+            d.append(v & ((1 << 29) - 1))
+            v >>= 29
+        return d + [v]
+    rng = random.Random(5)
+    lim = int(5.3 * P)
+    worst = 0.0
+    for trial in range(20000):
+        cols = [0] * 9
+        for c in coef:
+            if trial % 3 == 0:
+                x = lim if c > 0 else -lim
+            elif trial % 3 == 1:
+                x = -lim if c > 0 else lim
+            else:
+                x = rng.choice([lim, -lim, rng.randrange(-lim, lim)])
+            for k, d in enumerate(digits(x)):
+                cols[k] += d * c
+        for k, d in enumerate(digits(rng.randrange(P))):
+            cols[k] += d
+        V = sum(c << (29 * k) for k, c in enumerate(cols))
+        th = (cols[8] + (cols[7] >> 29)) >> SH
+        assert -2 ** 31 <= th < 2 ** 31
+        q = (th * M) >> 32
+        assert abs(q) < 2 ** 29 and max(abs(c) for c in cols) < 2 ** 62
+        worst = max(worst, abs(V - q * P) / P)
+    assert worst < 1.3, worst
 
 
 def test_digest_path_with_hoisted_tag_sbox(oracle_mod, hosttest_lib):
