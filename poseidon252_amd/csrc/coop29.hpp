@@ -53,9 +53,10 @@ P252_HD E29 coop_sbox_g(const E29& u, TP g, bool odd, const RK& K, Comm& cm) {
     for (int k = 0; k < NL; ++k) mine.d[k] = odd ? t1.d[k] : t2.d[k];
     const E29 other = cm.swap1(mine);
     // even: u^4 * (u G); odd: (u G) * u^4 — the same 81 digit products summed (exactly) into the same columns: identical bits
-    acc_zero_w(t, K);
+    // (W_q leaves as wide digits: it only meets the recurrence and the exit rows)
+    acc_zero_w<true>(t, K);
     acc_mul(t, mine, other.d);
-    return redc_w(t, K);
+    return redc_w<true>(t, K);
 }
 
 template <int QM, class Comm, class TP>
@@ -138,7 +139,7 @@ P252_HD void hades_permute_coop(E29& s, E29& s4, TP tab, Comm& cm, CoopLane<LANE
         for (int f = half * RF; f < (half + 1) * RF; ++f) {
             int32_t kap_next[NL];
             if (f != RF - 1) coop_load_kappa(kap_next, tab, (f + 1) % (2 * RF), L.row);  // (round 3 has no row: the entry)
-            const E29 x = sbox_w(s, K);
+            const E29 x = sbox_w<true>(s, K);  // (wide digits: the outputs only meet the integer rows)
             xs[0] = cm.template get<0>(x);
             xs[1] = cm.template get<1>(x);
             xs[2] = cm.template get<2>(x);
@@ -146,7 +147,7 @@ P252_HD void hades_permute_coop(E29& s, E29& s4, TP tab, Comm& cm, CoopLane<LANE
             if (LANES == 8)
                 xs[4] = cm.template get<4>(x);
             else
-                xs[4] = sbox_w(s4, K);
+                xs[4] = sbox_w<true>(s4, K);
             if (f != RF - 1) {
                 s = coop_int_row(xs, L.hn, L.kap);
                 if (LANES == 4 && (ROW4 || f != 2 * RF - 1))

@@ -263,12 +263,14 @@ P252_HD RK make_rk() {
         if ((i) + 8 < (NCOL)) (c)[(i) + 8] -= q * (int64_t)P252_PB_8;                     \
     }
 
-// accumulator for a product that will be reduced by redc_w: bias in the nine low columns
+// accumulator for a product that will be reduced by redc_w: bias in the nine low columns; WIDE (the result leaves as
+// wide digits, see redc_w): in the high columns 9..16 as well
+template <bool WIDE = false>
 P252_HD void acc_zero_w(A29& t, const RK& K) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
         t.c[k] = K.bias;
-        t.c[NL + k] = 0;
+        t.c[NL + k] = (WIDE && k < NL - 1) ? K.bias : (int64_t)0;
     }
 }
 template <class CP>
@@ -280,7 +282,15 @@ P252_HD void acc_set_hi_c_w(A29& t, CP c, const RK& K) {
     }
 }
 
-// nine wide steps + the carry chain over the high columns (digits 0..7 in [0, 2^29), top digit signed, |top| < 2^26)
+// nine wide steps + the carry chain over the high columns (digits 0..7 in [0, 2^29), top digit signed, |top| < 2^26).
+// WIDE = true: the result leaves as WIDE DIGITS instead — digit k = the whole low register of column 9 + k read as a signed
+// number (the bias trick of the wide step again: q = low register XOR 2^31, the rest of the column, 8 x its high register,
+// goes to the next column), |digit| <= 2^31: 2 instructions and 6 issue cycles per digit where the carry chain takes 3 and
+// 10.  Such a value may only be a MULTIPLICAND OF CONSTANTS — a generic product by balanced constant digits (|g| <= 2^28:
+// columns stay below 9 x 2^59 + 2^60.4) or one- / two-digit integer rows — never of another variable: the S-box outputs
+// of the full rounds (-> integer rows), x^5 of a partial round (-> G) and W_q (-> the recurrence, the exit rows).
+// tables.hpp max_column_bound29 charges 2^31 per digit for exactly those operands.
+template <bool WIDE = false>
 P252_HD E29 redc_w(A29& t, const RK& K) {
     P252_WSTEP(t.c, 0, 2 * NL, K)
     P252_WSTEP(t.c, 1, 2 * NL, K)
@@ -292,6 +302,19 @@ P252_HD E29 redc_w(A29& t, const RK& K) {
     P252_WSTEP(t.c, 7, 2 * NL, K)
     P252_WSTEP(t.c, 8, 2 * NL, K)
     E29 r;
+    if (WIDE) {
+#pragma unroll
+        for (int k = 0; k < NL - 1; ++k) {
+            P252_TRK_COL(t.c[NL + k]);
+            r.d[k] = opaque_digit((int32_t)((uint32_t)t.c[NL + k] ^ 0x80000000u));
+            const int64_t h = (int32_t)(t.c[NL + k] >> 32);
+            t.c[NL + k + 1] += h * (int64_t)K.eight;
+        }
+        P252_TRK_COL(t.c[2 * NL - 1]);
+        r.d[NL - 1] = opaque_digit((int32_t)t.c[2 * NL - 1]);
+        P252_TRK_TOP(r.d[NL - 1]);
+        return r;
+    }
     int64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < NL - 1; ++k) {
@@ -428,13 +451,14 @@ P252_HD E29 mul_c(const E29& x, CP n) {
     return redc(t);
 }
 
-// the same with the wide reduction (result within +-4.01 p of x n / R')
-template <class CP>
+// the same with the wide reduction (result within +-4.01 p of x n / R'); x may have wide digits (n: balanced constant
+// digits); WIDE_OUT: the result leaves as wide digits (redc_w)
+template <bool WIDE_OUT = false, class CP>
 P252_HD E29 mul_c_w(const E29& x, CP n, const RK& K) {
     A29 t;
-    acc_zero_w(t, K);
+    acc_zero_w<WIDE_OUT>(t, K);
     acc_mul(t, x, n);
-    return redc_w(t, K);
+    return redc_w<WIDE_OUT>(t, K);
 }
 
 // carry-normalise an element whose digits have drifted (after digit-wise additions)
@@ -488,7 +512,9 @@ P252_HD E29 sbox(const E29& x) {
     return redc(t);
 }
 
-// x^5 with wide reductions: |result| < 0.0142 (|x|/p)^2 ... all three stay below 4.4 p for |x| < 7p
+// x^5 with wide reductions: |result| < 0.0142 (|x|/p)^2 ... all three stay below 4.4 p for |x| < 7p.  WIDE_OUT: the result
+// leaves as wide digits (redc_w) — for outputs that only meet constants (every S-box of the kernels' schedule)
+template <bool WIDE_OUT = false>
 P252_HD E29 sbox_w(const E29& x, const RK& K) {
     A29 t;
     acc_zero_w(t, K);
@@ -497,9 +523,9 @@ P252_HD E29 sbox_w(const E29& x, const RK& K) {
     acc_zero_w(t, K);
     acc_sqr(t, x2);
     const E29 x4 = redc_w(t, K);
-    acc_zero_w(t, K);
+    acc_zero_w<WIDE_OUT>(t, K);
     acc_mul(t, x4, x.d);
-    return redc_w(t, K);
+    return redc_w<WIDE_OUT>(t, K);
 }
 
 // ---- conversion from / to the reference's memory format (4 x u64 Montgomery limbs, R = 2^256) ----

@@ -171,7 +171,7 @@ P252_HD void ai_recur(E29 Us[HIST], const E29 Ws[HIST], TP ab, TP kg, const RK& 
 }
 template <int QM /* q mod HIST */, class TP>
 P252_HD void ai_round(E29 Us[HIST], E29 Ws[HIST], TP ab, TP kg, const RK& K) {
-    Ws[QM] = mul_c_w(sbox_w(Us[QM], K), kg + NL, K);
+    Ws[QM] = mul_c_w<true>(sbox_w<true>(Us[QM], K), kg + NL, K);  // (wide digits: x^5 meets G, W_q the recurrence / exit rows)
     ai_recur<QM>(Us, Ws, ab, kg, K);
 }
 
@@ -315,11 +315,11 @@ P252_HD void hades_permute(E29 s[WIDTH], TP tab) {
             const TP kap = tab + Lay::AI_KAPPA + f * WIDTH * NL;
             E29 x[WIDTH];
 #pragma unroll
-            for (int j = 1; j < WIDTH; ++j) x[j] = sbox_w(s[j], K);
+            for (int j = 1; j < WIDTH; ++j) x[j] = sbox_w<true>(s[j], K);  // (wide digits: they only meet the integer rows)
             if (PRE0 && f == 0)  // (wave-uniform) first round of a digest: lane 0's S-box output came with the launch
                 x[0] = s[0];
             else
-                x[0] = sbox_w(s[0], K);
+                x[0] = sbox_w<true>(s[0], K);
             if (f == RF - 1) {  // the linear layer of round 3 is the entry below: hand over the S-box outputs
 #pragma unroll
                 for (int i = 0; i < WIDTH; ++i) s[i] = x[i];

@@ -628,11 +628,12 @@ inline double max_column_bound29(const int32_t* tab) {
     const double WSTEP = 2147483648.0 * ab(P252_PB_5);  // the largest single contribution of one wide step to a column
     double worst = 0;
     auto absd = [](int32_t v) { return v < 0 ? -(double)v : (double)v; };
-    auto group = [&](std::initializer_list<int> offsets) {  // sum of 9-digit x 9-digit products into 18 columns
+    const double WIDE = 2147483648.0;  // |wide digit| <= 2^31 (fr29.hpp redc_w<true>): S-box outputs, x^5 of a partial round, W_q
+    auto group = [&](std::initializer_list<int> offsets, bool wide = false) {  // sum of 9-digit x 9-digit products into 18 columns
         double col[2 * NL] = {0};
         for (int off : offsets)
             for (int j = 0; j < NL; ++j)
-                for (int i = 0; i < NL; ++i) col[i + j] += (i == NL - 1 ? TOP : DIG) * absd(tab[off + j]);
+                for (int i = 0; i < NL; ++i) col[i + j] += (i == NL - 1 ? TOP : (wide ? WIDE : DIG)) * absd(tab[off + j]);
         for (int k = 0; k < 2 * NL; ++k)
             if (col[k] + REDC > worst) worst = col[k] + REDC;
     };
@@ -649,7 +650,7 @@ inline double max_column_bound29(const int32_t* tab) {
     // (B), (C): generic products
     for (int q = 0; q < PARTIAL_ROUNDS; ++q) {
         group({Lay::INT_G + q * NL});
-        group({Lay::AI_KG + (q * 2 + 1) * NL});
+        group({Lay::AI_KG + (q * 2 + 1) * NL}, true);  // x^5 (wide digits) times G_q
     }
     group({Lay::INT_F});
     group({Lay::AI_F});
@@ -658,27 +659,27 @@ inline double max_column_bound29(const int32_t* tab) {
             group({Lay::AI_ENT_FIX + i * NL});
             double esum = 0;  // integer entry row: at most one digit product per coefficient digit per column, two digit steps
             for (int t = 0; t < 8; ++t) esum += absd(tab[Lay::AI_ENT_N + i * NL + t]);
-            const double erow = DIG * esum + 2.0 * WSTEP + 68719476736.0;
+            const double erow = WIDE * esum + 2.0 * WSTEP + 68719476736.0;  // (the S-box outputs of round 3: wide digits)
             if (erow > worst) worst = erow;
         }
         group({Lay::AI_EX_FIX + i * NL});
         // integer exit row: a column collects at most one digit product per coefficient digit (16 of them), then two digit steps
-        double nsum = 0;
-        for (int t = 0; t < 16; ++t) nsum += absd(tab[Lay::AI_EX_N + i * 2 * NL + t]);
-        const double row = DIG * nsum + 2.0 * WSTEP + 68719476736.0;
+        double nsum = 0;  // (coefficients 0..7 meet U_58..U_61: carried digits; 8..15 meet W_57..W_60: wide digits)
+        for (int t = 0; t < 16; ++t) nsum += (t < 8 ? DIG : WIDE) * absd(tab[Lay::AI_EX_N + i * 2 * NL + t]);
+        const double row = nsum + 2.0 * WSTEP + 68719476736.0;
         if (row > worst) worst = row;
     }
     {  // integer rows: five one-digit terms (row 0 has the largest sum) of possibly un-carried lanes + kappa + one digit step
         double nsum = 0;
         for (int j = 0; j < WIDTH; ++j) nsum += absd(tab[Lay::INT_N + j]);
-        const double row = LAZY * nsum + 268435456.0 + DIG * (double)P252_P29_1 + 68719476736.0;
+        const double row = (LAZY > WIDE ? LAZY : WIDE) * nsum + 268435456.0 + DIG * (double)P252_P29_1 + 68719476736.0;
         if (row > worst) worst = row;
     }
     {  // integer ARMA row: a column collects one digit of each of the nine terms (all at the same weight) and K's digit, then
         // the quotient of the reduction from the top (|q| < 2^29) times one balanced digit of p
-        double asum = 0;
-        for (int t = 0; t < NL; ++t) asum += absd(tab[Lay::AI_AB + t]);
-        const double row = DIG * asum + 536870912.0 * ab(P252_PB_5) + DIG + 68719476736.0;
+        double asum = 0;  // (A_1..A_4 meet U: carried digits; B_0..B_4 meet W: wide digits)
+        for (int t = 0; t < NL; ++t) asum += (t < 4 ? DIG : WIDE) * absd(tab[Lay::AI_AB + t]);
+        const double row = asum + 536870912.0 * ab(P252_PB_5) + DIG + 68719476736.0;
         if (row > worst) worst = row;
     }
     // S-box: element x element (9 products of 2^29 x 2^29) and squarings (<= 4.5 * 2^59)
