@@ -21,8 +21,8 @@ def test_committed_isa_counts_match_the_sources():
             assert now[key] == committed[kernel][key], (kernel, key, now[key], committed[kernel][key])
     m4, pm = committed["k_merkle4"], committed["k_permute"]
     # one v_mad_i64_i32 per digit product: 100 S-boxes minus the hoisted one, 60 G-products, ...
-    assert 58_000 < m4["v_mad_i64_i32"] < 61_000 and m4["v_mad_i64_i32"] < pm["v_mad_i64_i32"]
-    assert m4["valu_total"] < 79_000  # round 1: 84,606; round 2: 80,386
+    assert 59_000 < m4["v_mad_i64_i32"] < 62_000 and m4["v_mad_i64_i32"] < pm["v_mad_i64_i32"]
+    assert m4["valu_total"] < 77_500  # round 1: 84,606; round 2: 80,386
     # the cooperative digest (eight lanes per node): about two thirds of the one-lane instruction stream per lane
     co, c4 = committed["k_merkle4_coop<8>"], committed["k_merkle4_coop<4>"]
     assert co["valu_total"] < 0.67 * m4["valu_total"] and co["v_mad_i64_i32"] < 0.65 * m4["v_mad_i64_i32"]
