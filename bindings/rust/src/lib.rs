@@ -110,6 +110,9 @@ pub struct Context(*mut P252Ctx);
 
 impl Context {
     pub fn new(device_id: i32) -> Self {
+        // argument lists changed between library versions under unchanged names: never call into another interface
+        let abi = unsafe { p252_abi_version() };
+        assert_eq!(abi, P252_ABI_VERSION, "libposeidon252_hip.so implements ABI version {abi}, this crate was generated for {P252_ABI_VERSION}");
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { p252_create(device_id as c_int, &mut ctx) };
         assert_eq!(rc, P252_OK, "poseidon252_hip: {} (this backend has no CPU fallback)", last_error(core::ptr::null()));

@@ -57,6 +57,14 @@ fn chunked_updates_and_the_tag_input_encoding() {
     let (t2, log2) = hash_tag(Domain::Other, &[3, 39], 1).unwrap();
     println!("tag input [Absorb(42), Squeeze(1)]            = {:02x?}", log1.tag_input);
     println!("tag input [Absorb(3), Absorb(39), Squeeze(1)] = {:02x?}", log2.tag_input);
+    // machine-readable (run_parity.sh collects these lines into RUSTPARITY.json)
+    println!("RUSTPARITY tag_input {{\"pattern\": \"other_42_1\", \"bytes\": {:?}, \"tag_limbs\": {:?}}}", log1.tag_input, t1.0);
+    println!("RUSTPARITY tag_input {{\"pattern\": \"other_3+39_1\", \"bytes\": {:?}, \"tag_limbs\": {:?}}}", log2.tag_input, t2.0);
+    for (name, domain, lens, out) in [("merkle4_4_1", Domain::Merkle4, vec![4usize], 1usize), ("merkle2_2_1", Domain::Merkle2, vec![2], 1),
+                                      ("other_42_5", Domain::Other, vec![42], 5)] {
+        let (t, log) = hash_tag(domain, &lens, out).unwrap();
+        println!("RUSTPARITY tag_input {{\"pattern\": \"{name}\", \"bytes\": {:?}, \"tag_limbs\": {:?}}}", log.tag_input, t.0);
+    }
     assert_eq!(t1, t2, "dusk-safe aggregates adjacent absorb calls");
     // the library's own helper (UNPINNED until this passes)
     let lens = [42usize];
@@ -102,6 +110,8 @@ mod encryption {
             let stream = encrypt_batch(&ctx, P252_CRYPT_STREAM, &msgs, len, &secrets, &nonces).unwrap();
             let duplex = encrypt_batch(&ctx, P252_CRYPT_DUPLEX, &msgs, len, &secrets, &nonces).unwrap();
             println!("len {len}: STREAM matches dusk-safe: {}, DUPLEX matches: {}", stream == expected, duplex == expected);
+            println!("RUSTPARITY encryption {{\"len\": {len}, \"stream\": {}, \"duplex\": {}, \"tag_input\": {:?}, \"permutations\": {}}}",
+                     stream == expected, duplex == expected, log.tag_input, log.permutations);
             assert!(stream == expected || duplex == expected, "neither candidate is dusk-safe's construction");
             let variant = if stream == expected { P252_CRYPT_STREAM } else { P252_CRYPT_DUPLEX };
             let back = decrypt_batch(&ctx, variant, &expected, len, &secrets, &nonces).unwrap();

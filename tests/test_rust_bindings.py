@@ -45,3 +45,32 @@ def test_lib_rs_calls_only_declared_functions_and_no_private_dusk_api():
     for shape in ("(Domain::Other, 3, 3, ", "(Domain::Other, 5, 2, ", "(Domain::Other, 4, 7, ", "[2usize, 21, 42]",
                   "(Domain::Merkle4, 4, 1, 20_000)"):  # the reference's tests/hash.rs shapes; a batch beyond the lane-group kernels
         assert shape in parity, shape
+
+
+def test_run_parity_script_names_only_files_that_exist():
+    """bindings/rust/run_parity.sh cannot run here (no cargo): at least every repository path it and
+    RUN.md name exists, the script is valid bash, its collector is valid Python, and parity.rs prints the lines it collects"""
+    rust = os.path.join(ROOT, "bindings", "rust")
+    script = open(os.path.join(rust, "run_parity.sh")).read()
+    assert subprocess.run(["bash", "-n", os.path.join(rust, "run_parity.sh")]).returncode == 0
+    py = re.search(r"<<'PY'\n(.*?)\nPY\n", script, re.S).group(1)
+    compile(py, "run_parity collector", "exec")
+    for rel in ("poseidon252_amd/build.py", "bindings/rust/Cargo.toml", "bindings/rust/build.rs", "bindings/rust/src/lib.rs", "bindings/rust/src/sys.rs",
+                "bindings/rust/tests/parity.rs", "bindings/rust/.cargo/config.toml", "bindings/rust/RUN.md"):
+        assert os.path.exists(os.path.join(ROOT, rel)), rel
+    assert "python -m poseidon252_amd.build" in script and "cargo test --release" in script and "RUSTPARITY.json" in script
+    assert "run_parity.sh" in open(os.path.join(rust, "RUN.md")).read()
+    parity = open(os.path.join(rust, "tests", "parity.rs")).read()
+    assert parity.count("RUSTPARITY tag_input") >= 3 and "RUSTPARITY encryption" in parity
+    # the collector understands the lines parity.rs prints
+    sample = ('test gpu_matches_reference_hash ... ok\nRUSTPARITY tag_input {"pattern": "merkle4_4_1", "bytes": [128, 0, 0, 4], "tag_limbs": [1, 2, 3, 4]}\n'
+              'RUSTPARITY encryption {"len": 21, "stream": true, "duplex": false, "tag_input": [1], "permutations": 13}\n')
+    import json, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "RUSTPARITY.log"), "w").write(sample)
+        r = subprocess.run([sys.executable, "-c", py, "0"], cwd=d, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        out = json.load(open(os.path.join(d, "RUSTPARITY.json")))
+    assert out["ok"] and out["tests"] == {"gpu_matches_reference_hash": "ok"} and out["encryption"]["21"]["stream"] is True
+    assert out["tag_inputs"]["merkle4_4_1"]["bytes"] == [128, 0, 0, 4]
+    assert "p252_abi_version()" in open(os.path.join(rust, "src", "lib.rs")).read()
