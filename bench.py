@@ -135,8 +135,16 @@ def pmc_traffic(kernel, workload, units_per_launch):
     if d["stale"]:
         return {"bytes": None, "stale_source": d["source"], "note": "the committed counter pass belongs to other kernel sources"}
     scale = units_per_launch / d["units_per_launch"]
-    return {"bytes": d["hbm_bytes_per_launch"] * scale, "algorithmic_bytes": BYTES_PER_PERM[workload] * units_per_launch,
-            "ratio": d["hbm_bytes_per_launch"] * scale / (BYTES_PER_PERM[workload] * units_per_launch), "source": d["source"]}
+    out = {"bytes": d["hbm_bytes_per_launch"] * scale, "algorithmic_bytes": BYTES_PER_PERM[workload] * units_per_launch,
+           "ratio": d["hbm_bytes_per_launch"] * scale / (BYTES_PER_PERM[workload] * units_per_launch), "source": d["source"]}
+    if workload == "tree":
+        # SURVEY §8d's figure counts the leaves in and the root out; a level-by-level build also writes every level and reads it
+        # back (nodes x 64 B): that is what the counters must be compared with to see wasted re-reads
+        lbl = BYTES_PER_PERM[workload] * units_per_launch + 64.0 * (units_per_launch - 1)
+        out["level_by_level_bytes"] = lbl
+        out["ratio_level_by_level"] = out["bytes"] / lbl
+        out["note"] = "ratio is against SURVEY's leaves-in + root-out figure; the build is level by level, which writes and re-reads every level"
+    return out
 
 
 def pmc_valu(kernel):

@@ -29,6 +29,15 @@ def main(path, title="", warm=10):
             print("%-60s %8d %12.1f %12.1f %12.1f %14.1f" % (name.split("(")[0][-58:], len(rest), sum(rest) / len(rest) / 1e3, min(rest) / 1e3,
                                                              max(rest) / 1e3, sum(head) / len(head) / 1e3))
     print()
+    print("# the library's kernels per launch size (one default bench.py run launches several: configs[1]'s 2^20 digests, the tree's")
+    print("# twelve levels, the sponge).  `steady` = the launches after the first %d of that size (wake-up, warm-up, probe steps)." % warm)
+    print("%-44s %10s %7s %12s %12s %12s %12s" % ("kernel", "grid", "calls", "avg_us", "min_us", "steady_calls", "steady_avg_us"))
+    for name, grid in list(cur.execute("select name, grid_x from kernels where name like '%p252::%' group by name, grid_x order by name, grid_x desc")):
+        durs = [r[0] for r in cur.execute("select duration from kernels where name = ? and grid_x = ? order by start", (name, grid))]
+        rest = durs[warm:] if len(durs) > warm + 1 else []
+        print("%-44s %10d %7d %12.1f %12.1f %12s %12s" % (name.split("(")[0][-42:], grid, len(durs), sum(durs) / len(durs) / 1e3, min(durs) / 1e3,
+                                                         len(rest) if rest else "-", ("%.1f" % (sum(rest) / len(rest) / 1e3)) if rest else "-"))
+    print()
     print("# per-kernel launch geometry / registers (first dispatch)")
     for r in cur.execute("select name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size from kernels group by name"):
         print("%-60s grid=%d wg=%d vgpr=%s agpr=%s sgpr=%s lds=%s scratch=%s" % ((r[0].split("(")[0][-58:],) + tuple(r[1:])))

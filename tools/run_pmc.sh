@@ -12,7 +12,10 @@ shift || true
 PASSES=${*:-valu itype wait fetch write ktrace}
 mkdir -p "$O/summaries"
 EXTRA=""
-[ "$WL" = tree ] && EXTRA="--no-check"  # a tree step is 12 launches: nothing but full builds may be in the trace (pmc_summary --per-step)
+TAG=$WL
+# LOG2N=12 bash tools/run_pmc.sh merkle4_digests valu  -> the lane-group kernel of small batches (k_merkle4_coop<8>)
+if [ -n "${LOG2N:-}" ]; then EXTRA="--log2n $LOG2N"; TAG=${WL}_$LOG2N; fi
+[ "$WL" = tree ] && EXTRA="$EXTRA --no-check"  # a tree step is 12 launches: nothing but full builds may be in the trace (pmc_summary --per-step)
 cd /tmp && export TMPDIR=/tmp
 counters() {
     case $1 in
@@ -31,13 +34,13 @@ counters() {
 }
 for p in $PASSES; do
     if [ "$p" = ktrace ]; then
-        rm -rf "$O/ktrace_$WL"
-        timeout 300 rocprofv3 --kernel-trace --stats -d "$O/ktrace_$WL" -o kt -- \
-            python "$ROOT/bench.py" --workload "$WL" --no-cpu-baseline $EXTRA > "$O/ktrace_$WL.log" 2>&1
+        rm -rf "$O/ktrace_$TAG"
+        timeout 300 rocprofv3 --kernel-trace --stats -d "$O/ktrace_$TAG" -o kt -- \
+            python "$ROOT/bench.py" --workload "$WL" --no-cpu-baseline $EXTRA > "$O/ktrace_$TAG.log" 2>&1
     else
-        rm -rf "$O/pmc_${WL}_$p"
-        timeout 300 rocprofv3 --pmc $(counters $p) --kernel-trace --output-format csv -d "$O/pmc_${WL}_$p" -o pmc -- \
-            python "$ROOT/bench.py" --workload "$WL" --steps 5 --warmup 1 --no-cpu-baseline $EXTRA > "$O/pmc_${WL}_$p.log" 2>&1
+        rm -rf "$O/pmc_${TAG}_$p"
+        timeout 300 rocprofv3 --pmc $(counters $p) --kernel-trace --output-format csv -d "$O/pmc_${TAG}_$p" -o pmc -- \
+            python "$ROOT/bench.py" --workload "$WL" --steps 5 --warmup 1 --no-cpu-baseline $EXTRA > "$O/pmc_${TAG}_$p.log" 2>&1
     fi
     echo "pass $p rc=$?"
 done
@@ -52,8 +55,9 @@ case $WL in  # dominant kernel, permutations per launch, algorithmic bytes per p
     *) K=k_merkle4; U=$U20; B=96 ;;
 esac
 PS=${PS:-}; NAME=${NAME:-$K}
-dirs=""; for d in "$O"/pmc_${WL}_*; do [ -f "$d/pmc_counter_collection.csv" ] && dirs="$dirs $d"; done
+if [ -n "${LOG2N:-}" ] && [ "$WL" = merkle4_digests ] && [ "$LOG2N" -le 13 ]; then K=k_merkle4_coop; U=$((1 << LOG2N)); NAME=k_merkle4_coop8; fi
+dirs=""; for d in "$O"/pmc_${TAG}_[a-z]*; do [ -f "$d/pmc_counter_collection.csv" ] && dirs="$dirs $d"; done
 [ -n "$dirs" ] && python tools/pmc_summary.py $K $U --bytes-per-unit $B $PS $dirs > "$O/summaries/pmc_$NAME.txt" 3> "$O/summaries/pmc_$NAME.json"
-db=$(find "$O/ktrace_$WL" -name "*.db" 2>/dev/null | head -1)
-[ -n "$db" ] && python tools/rocprof_summary.py "$db" "bench.py --workload $WL" > "$O/summaries/ktrace_$WL.txt"
+db=$(find "$O/ktrace_$TAG" -name "*.db" 2>/dev/null | head -1)
+[ -n "$db" ] && python tools/rocprof_summary.py "$db" "bench.py --workload $WL" > "$O/summaries/ktrace_$TAG.txt"
 ls "$O/summaries"
