@@ -369,9 +369,9 @@ def make_workload(E, wl, log2n):
         W.step = lambda: ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
     elif wl == "tree":
         d_out = torch.empty(4, dtype=torch.int64, device=dev)
-        if world == 1:
+        if not dist.is_initialized():
             W.step = lambda: ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
-        else:
+        else:  # (also at one rank when a process group exists — P252_BENCH_FORCE_DIST: the RCCL all-gather on a 1-GPU box)
             # BASELINE configs[4] structure: every rank reduces its complete subtree, the W roots (32 B each)
             # are all-gathered (the path's only exchange step) and the top levels are hashed on every rank
             coll_dev = E.coll_dev
@@ -699,7 +699,7 @@ def main():
                 "unit": "permutations/s", "n_gpus": world,
                 "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                 "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
-                "exchange": ("all-gather of %d x 32-byte subtree roots per step" % world) if (key == "tree" and world > 1) else None,
+                "exchange": ("all-gather of %d x 32-byte subtree roots per step" % world) if (key == "tree" and dist.is_initialized()) else None,
                 "roofline": r2, "self_consistency_ok": ok2, "parity_sample_ok": None,
             }
         del W2

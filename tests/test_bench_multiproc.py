@@ -119,11 +119,16 @@ def test_bench_rccl_backend_single_rank(gpu_ctx):
     env = dict(os.environ, P252_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
-                                   "--log2n", "14", "--no-cpu-baseline"], cwd=ROOT, env=env, timeout=600,
+                                   "--log2n", "14", "--secondary-log2n", "12", "--no-cpu-baseline"], cwd=ROOT, env=env, timeout=600,
                                   stderr=subprocess.DEVNULL)
     d = _one_json_line(out)
     assert d["n_gpus"] == 1 and d["self_consistency_ok"] is True
     assert "identical to local derivation: True" in d["config"]["constants"]
+    # the secondary tree takes the sharded path whenever a process group exists: subtree root -> RCCL all-gather (of one
+    # root here) -> top levels — the collective of BASELINE configs[4] on the real backend
+    t = d["secondary"]["tree"]
+    assert t["collective_backend"] == "nccl" and "all-gather of 1 x 32-byte subtree roots" in t["exchange"] and t["self_consistency_ok"] is True
+    assert t["units_per_gpu_per_step"] == (4 ** 8 - 1) // 3 and d["secondary"]["sponge42"]["self_consistency_ok"] is True
 
 
 def test_bench_tree_two_ranks_gather_roots(gpu_ctx):
