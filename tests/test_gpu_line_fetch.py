@@ -26,8 +26,11 @@ def test_sponge_line_fetch_matches_oracle(gpu_ctx, oracle_mod, in_len, out_len):
     # (32 B: messages no longer start on 64-byte boundaries -> the block-by-block kernel)
     flat = torch.from_numpy(np.concatenate([np.zeros((1, 4), dtype=np.uint64), m.reshape(-1, 4)]).view(np.int64)).cuda()
     d_al = flat[1:].clone()
-    assert d_al.data_ptr() % 128 == 0 and flat[1:].data_ptr() % 64 == 32
-    for d_in in (d_al, flat[1:]):
+    # ... and at an offset of two scalars (64 B): still the whole-line kernel, with the roles of the lanes exchanged (for
+    # in_len = 4 k EVERY message then starts and ends in mid-line)
+    flat2 = torch.from_numpy(np.concatenate([np.zeros((2, 4), dtype=np.uint64), m.reshape(-1, 4)]).view(np.int64)).cuda()
+    assert d_al.data_ptr() % 128 == 0 and flat[1:].data_ptr() % 64 == 32 and flat2[2:].data_ptr() % 128 == 64
+    for d_in in (d_al, flat[1:], flat2[2:]):
         d_out = torch.zeros((N, out_len, 4), dtype=torch.int64, device="cuda")
         gpu_ctx.hash_batch_device(tag, d_in, in_len, out_len, d_out, N)
         torch.cuda.synchronize()
