@@ -73,6 +73,10 @@ inline void check(int rc, p252_ctx* ctx, const char* what) {
 class Context {
   public:
     explicit Context(int device = 0) {
+        // argument lists have changed between library versions under unchanged names: never call into another interface
+        if (p252_abi_version() != P252_ABI_VERSION)
+            throw DeviceError("libposeidon252_hip.so implements ABI version " + std::to_string(p252_abi_version()) +
+                              ", this header is version " + std::to_string(P252_ABI_VERSION));
         p252_ctx* c = nullptr;
         const int rc = p252_create(device, &c);
         if (rc != P252_OK) throw DeviceError(std::string("p252_create: ") + p252_last_error(nullptr));

@@ -27,6 +27,7 @@ int main(void) {
     uint64_t sep = 0, tag[4], tag2[4];
     size_t four = 4, lens2[2] = {1, 3};
     printf("%s\n", p252_version());
+    CHECK(p252_abi_version() == P252_ABI_VERSION); /* the library this binary loads implements the header it was compiled against */
     CHECK(p252_domain_separator(P252_DOMAIN_MERKLE4, &sep) == P252_OK && sep == 0xf);
     CHECK(p252_domain_separator(P252_DOMAIN_ENCRYPTION, &sep) == P252_OK && sep == 0x100000000ULL);
     CHECK(p252_check_io_pattern(P252_DOMAIN_MERKLE4, &four, 1, 1) == P252_OK);
