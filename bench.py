@@ -19,6 +19,8 @@ runs this one command:
                       reduces its subtree, the N roots (32 B each) are all-gathered — the path's only exchange step —
                       and the top levels are hashed on every rank: at N = 8 that IS configs[4] (2^27 leaves)
   secondary.sponge42  BASELINE configs[3]: Domain::Other sponge, 2^20 messages x 42 scalars -> 5 outputs per GPU
+  secondary.openings  SURVEY §8 f3: 2^20 Merkle4 openings of depth 12 per GPU (branch re-hash, k_merkle4_path_lines)
+  secondary.encrypt   SURVEY §8 f4: 2^20 encryptions of 2-scalar messages per GPU (k_crypt; construction unpinned)
 (--no-secondary skips them; --workload X makes X the primary and runs no secondary; --log2n scales the primary.)
 
 The shader clock is MEASURED inside the run: a one-wave probe kernel (p252_clock_probe_device: s_memtime
@@ -636,7 +638,8 @@ def main():
     E = Env(torch, dist, ctx, dev, coll_dev, rank, world)
 
     primary_key = args.workload or "merkle4_digests"
-    secondary_keys = [] if (args.workload or args.no_secondary) else ["tree", "sponge42"]
+    # BASELINE configs[2] / [3] (configs[4] at 8 ranks), then the SURVEY §8(f) rows that have kernels of their own
+    secondary_keys = [] if (args.workload or args.no_secondary) else ["tree", "sponge42", "openings", "encrypt"]
     sclk0 = sysfs_sclk_mhz(torch, local_rank)
 
     def measure(key, log2n, steps, warmup):

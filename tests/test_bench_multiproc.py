@@ -68,8 +68,11 @@ def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
         assert k in d, k
     assert "BASELINE configs[1]" in d["config"]["workload"] and d["self_consistency_ok"] is True
     sec = d["secondary"]
-    assert sorted(sec) == ["sponge42", "tree"]
+    assert sorted(sec) == ["encrypt", "openings", "sponge42", "tree"]
     t, s = sec["tree"], sec["sponge42"]
+    for w, kern, units in ((sec["openings"], "k_merkle4_path_lines", 12 << 14), (sec["encrypt"], "k_crypt", 2 << 14)):
+        assert w["roofline"]["kernel"] == kern and w["units_per_gpu_per_step"] == units
+        assert w["self_consistency_ok"] is True and w["parity_sample_ok"] is True and w["value"] > 1e6
     assert "2^18-leaf arity-4 Merkle tree" in t["workload"]
     assert t["units_per_gpu_per_step"] == (4 ** 9 - 1) // 3  # 4^9 leaves: 65536 + 16384 + ... + 4 + 1 = 87381 nodes
     assert s["units_per_gpu_per_step"] == 12 << 14 and "42 scalars -> 5 outputs" in s["workload"]
@@ -80,7 +83,7 @@ def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
         _check_clock(w["roofline"])
     assert t["roofline"]["kernel"] == "k_merkle4" and s["roofline"]["kernel"] == "k_sponge_lines"
     cb = d["cpu_baseline"]
-    assert cb["parity_samples"] == {"merkle4_digests": True, "tree": True, "sponge42": True} and cb["parity_sample_ok"] is True
+    assert cb["parity_samples"] == {"merkle4_digests": True, "tree": True, "sponge42": True, "openings": True, "encrypt": True} and cb["parity_sample_ok"] is True
     assert cb["threads"] == cb["cores"] >= 1 and "cpu_quota" in cb and cb["cpus_visible"] >= 1
 
 

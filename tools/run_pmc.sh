@@ -49,7 +49,7 @@ U20=1048576
 case $WL in  # dominant kernel, permutations per launch, algorithmic bytes per permutation
     merkle4_digests) K=k_merkle4; U=$U20; B=160 ;;
     sponge42) K=k_sponge; U=$((12 * U20)); B=125.3333 ;;
-    openings) K=k_merkle4_path; U=$((12 * U20)); B=99.3333 ;;
+    openings) K=k_merkle4_path; U=$((12 * U20)); B=102.3333 ;;  # (32 leaf + 12 x 96 siblings + 12 position bytes + 32 root) / 12
     encrypt) K=k_crypt; U=$((2 * U20)); B=128 ;;
     tree) K=k_merkle4; U=5592405; B=96.0000057; PS=--per-step; NAME=tree ;;
     *) K=k_merkle4; U=$U20; B=96 ;;
