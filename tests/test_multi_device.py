@@ -135,7 +135,8 @@ def test_multi_contexts_share_the_cpu_budget(gpu_ctx, ctxs, oracle_mod):
     added = peak[0] - base_threads - 1
     print("host->host digests/s: 1 context %.3g, 8 contexts %.3g (%.2f x), lanes per context %d, threads added %d"
           % (single, eight, eight / single, per8, added))
-    assert added <= 8 * per8 - 1 + 1, (added, per8)  # (+1: a HIP runtime helper thread may appear)
+    assert added <= 8 * per8 + 2, (added, per8)  # 8 x lanes workers, one of them the caller (a HIP runtime helper thread or two may appear)
+    assert added < 24 + 7, added  # (round 2: 24 workers + 7 drivers)
     assert eight > 1.0e8, eight  # one lane alone moves 1.66e8 (1.0e8 on a busy host): anything below means the contexts serialised each other
 
 
