@@ -186,6 +186,42 @@ def usable_cpus():
     return max(1, n)
 
 
+def reference_cargo_bench():
+    """the reference's OWN CPU figure: `cargo bench --features=zk --bench hash -- "hash 4 BlsScalar"`
+    (/root/reference/benches/hash.rs:68-72,93-97; Cargo.toml:50-53) — probed at run time on this box, not assumed: it needs cargo +
+    rustc, the reference tree (P252_REFERENCE_DIR, default /root/reference; it does not travel to the GPU box) and the dusk
+    crates resolvable offline (a vendored registry).  Returns the criterion figure when all of that is present, otherwise what
+    was missing."""
+    import shutil
+    import subprocess
+    probe = {"cargo": shutil.which("cargo"), "rustc": shutil.which("rustc")}
+    ref = os.environ.get("P252_REFERENCE_DIR", "/root/reference")
+    probe["reference_dir"] = ref if os.path.exists(os.path.join(ref, "Cargo.toml")) else None
+    reg = [d for d in (os.path.join(os.path.expanduser("~"), ".cargo", "registry"), os.path.join(ref, "vendor"),
+                       os.path.join(ROOT, "bindings", "rust", "vendor")) if os.path.isdir(d)]
+    probe["crate_registry"] = reg[0] if reg else None
+    missing = [k for k, v in probe.items() if not v]
+    out = {"available": False, "probe": probe, "command": 'cargo bench --features=zk --bench hash -- "hash 4 BlsScalar"'}
+    if missing:
+        out["why"] = "not on this box: " + ", ".join(missing)
+        return out
+    try:
+        r = subprocess.run(["cargo", "bench", "--offline", "--features=zk", "--bench", "hash", "--", "hash 4 BlsScalar"], cwd=ref,
+                           capture_output=True, timeout=900, env=dict(os.environ, CARGO_TARGET_DIR=os.path.join("/tmp", "p252_ref_target")))
+    except (OSError, subprocess.TimeoutExpired) as e:
+        out["why"] = "cargo bench did not finish: %r" % (e,)
+        return out
+    import re
+    m = re.search(r"time:\s*\[\s*([0-9.]+)\s*(ns|µs|us|ms)\s+([0-9.]+)\s*(ns|µs|us|ms)\s+([0-9.]+)\s*(ns|µs|us|ms)", r.stdout.decode(errors="replace"))
+    if r.returncode != 0 or not m:
+        out["why"] = "cargo bench failed (rc %d): %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])
+        return out
+    scale = {"ns": 1e-9, "us": 1e-6, "µs": 1e-6, "ms": 1e-3}
+    med = float(m.group(3)) * scale[m.group(4)]
+    return {"available": True, "probe": probe, "command": out["command"], "seconds_per_hash_median": med, "value": 1.0 / med,
+            "unit": "permutations/s", "cores": 1, "kind": "reference"}
+
+
 def cpu_baseline(tag, gpu_samples=()):
     """The oracle (C restatement of the reference CPU path, reference schedule: 2000 mults/perm) on the
     host cores.  Bounded sample: 2^12 digests on 1 thread, then 2^14 per thread on all threads.
@@ -252,17 +288,21 @@ def cpu_baseline(tag, gpu_samples=()):
             exp = oracle.hash_batch(stag, inp, in_len, out_len)
         parity[name] = bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(exp).reshape(-1)))
     quota = cpu_quota()
+    granted = usable_cpus()  # CPUs this process can actually run on at once: min(affinity mask, cgroup quota)
     return {"parity_sample_ok": (all(parity.values()) if parity else None), "parity_samples": parity,
             "value": nall / best, "unit": "permutations/s",
-            # `cores` (the contract's key) = the THREADS the multi-threaded figure used — the count that ran fastest; the
-            # box grants fewer CPUs than that through its cgroup quota (cpu_quota) and shows many more (cpus_visible)
-            "cores": threads, "threads": threads, "cpu_quota": quota, "cpus_visible": os.cpu_count(), "kind": "port",
+            # `cores` (the contract's key) = the CPUs the box GRANTS this process (cgroup quota / affinity): the figure is bound by
+            # them, not by the `threads` the fastest run started (oversubscribing a quota hides its throttling pauses) nor by the
+            # cpus_visible; value_per_quota_cpu = value / cores, to be compared with value_1core (one unthrottled core)
+            "cores": granted, "threads": threads, "cpu_quota": quota, "cpus_visible": os.cpu_count(), "kind": "port",
+            "value_per_quota_cpu": nall / best / granted,
+            "reference_cargo_bench": reference_cargo_bench(),
             "sample": "Hash::digest(Merkle4, 4 scalars): %d digests per sample on %d threads, 1 thread: %d digests per sample; "
                       "warm-up + 10 samples each, median reported (min in *_min)" % (nall, threads, n1),
             "value_min_time": nall / float(np.min(allt)), "value_1core": n1 / t1, "value_1core_min_time": n1 / float(np.min(one)),
             "cpu": cpu_model, "compiler": "gcc " + flags,
-            "note": "C restatement of the reference CPU path (oracle/p252_oracle.c, reference schedule); "
-                    "the Rust reference cannot be built here (no cargo; un-vendored crates)"}
+            "note": "C restatement of the reference CPU path (oracle/p252_oracle.c, reference schedule: 2,000 field multiplications per "
+                    "permutation); the reference's own cargo bench is probed at run time: see reference_cargo_bench"}
 
 
 def _free_port():
@@ -292,6 +332,29 @@ class Env:
     def __init__(self, torch, dist, ctx, dev, coll_dev, rank, world):
         self.torch, self.dist, self.ctx, self.dev, self.coll_dev, self.rank, self.world = torch, dist, ctx, dev, coll_dev, rank, world
         self.side = torch.cuda.Stream(device=dev)  # the clock probe's stream
+        self._comm, self.library_comm_error = None, None
+
+    def library_comm(self):
+        """this rank's p252_comm over all ranks (created once: ncclCommInitRank inside the library, rank 0's id handed round
+        through the torch.distributed process group; the creation itself broadcasts and validates the constant table over
+        RCCL) — only with the nccl backend, i.e. one rank per GPU; None with gloo (ranks sharing a GPU in the tests)"""
+        if self._comm is None and self.library_comm_error is None:
+            if not self.dist.is_initialized() or self.dist.get_backend() != "nccl" or os.environ.get("P252_BENCH_TORCH_GATHER") == "1":
+                self.library_comm_error = ""
+                return None
+            from poseidon252_amd import comm as C
+            try:
+                self._comm = C.Comm.create_rank(self.ctx, self.rank, self.world, C.torch_exchange(self.coll_dev))
+            except Exception as e:  # reported in the JSON line; the torch.distributed (also RCCL) exchange takes over
+                self.library_comm_error = repr(e)
+                print("bench.py rank %d: library communicator failed: %r" % (self.rank, e), file=sys.stderr)
+            # every rank must take the same path: one failure anywhere sends all of them to the torch exchange
+            ok = self.torch.tensor([1 if self._comm is not None else 0], dtype=self.torch.int32, device=self.coll_dev)
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and self._comm is not None:
+                self._comm.destroy()
+                self._comm, self.library_comm_error = None, "another rank failed to create its communicator"
+        return self._comm
 
     def barrier(self):
         if self.dist.is_initialized():
@@ -304,6 +367,16 @@ class Env:
         t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.coll_dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def per_rank(self, seconds):
+        """every rank's own wall time of the timed region (the same barriers bracket all of them, so the spread is the
+        ranks' imbalance: a scaling curve can be read for balance, not only for the slowest rank)"""
+        if not self.dist.is_initialized():
+            return [seconds]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.coll_dev)
+        t[self.rank] = seconds
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
 
 
 class Workload:
@@ -377,20 +450,36 @@ def make_workload(E, wl, log2n):
             # BASELINE configs[4] structure: every rank reduces its complete subtree, the W roots (32 B each)
             # are all-gathered (the path's only exchange step) and the top levels are hashed on every rank
             coll_dev = E.coll_dev
-            d_roots = torch.empty(world * 4, dtype=torch.int64, device=coll_dev)  # flat: gloo and nccl both accept it
             d_top = torch.empty(4, dtype=torch.int64, device=dev)
             W.d_top = d_top
+            comm = E.library_comm()
+            if comm is not None:
+                # RCCL INSIDE the library (p252_merkle4_tree_sharded_device): subtree -> ncclAllGather of the roots on the
+                # launch stream -> top levels, one call, no host round trip and no Python between the launches
+                W.exchange_impl = "ncclAllGather inside libposeidon252_hip.so (p252_merkle4_tree_sharded_device), on the launch stream"
+                W.step = lambda: comm.merkle4_tree_sharded_device(tag, d_in, n, d_top)
+            else:
+                # torch.distributed collective between two library calls: the gloo test configuration (ranks sharing one
+                # GPU — RCCL refuses two ranks on a device), or a library communicator that could not be created (reported)
+                W.exchange_impl = "torch.distributed.all_gather_into_tensor (%s)%s" % (
+                    dist.get_backend(), "; library communicator unavailable: " + E.library_comm_error if E.library_comm_error else "")
+                d_roots = torch.empty(world * 4, dtype=torch.int64, device=coll_dev)  # flat: gloo and nccl both accept it
 
-            def step():
-                ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
-                dist.all_gather_into_tensor(d_roots, d_out if coll_dev == dev else d_out.cpu())
-                roots_dev = d_roots if coll_dev == dev else d_roots.to(dev)
-                ctx.merkle4_tree_device(tag, roots_dev.contiguous(), world, d_top, None)
-            W.step = step
+                def step():
+                    ctx.merkle4_tree_device(tag, d_in, n, d_out, None)
+                    dist.all_gather_into_tensor(d_roots, d_out if coll_dev == dev else d_out.cpu())
+                    roots_dev = d_roots if coll_dev == dev else d_roots.to(dev)
+                    ctx.merkle4_tree_device(tag, roots_dev.contiguous(), world, d_top, None)
+                W.step = step
+            # whole-job units of one step: every rank's subtree + the top levels ONCE (every rank hashes the same
+            # levels_len(world) top nodes redundantly; they are not counted `world` times)
+            W.job_units_per_step = world * W.perms_per_step + P.levels_len(world)
             W.perms_per_step += P.levels_len(world)
             W.name += " + all-gather of %d subtree roots and top levels" % world
-            if world == 8 and log2n == 24:
-                W.name += " = 2^27-leaf tree sharded across 8 GPUs (BASELINE configs[4])"
+            if world == 8:
+                W.name += (" = 2^27-leaf tree sharded across 8 GPUs (BASELINE configs[4])" if log2n == 24 else
+                           " = the BASELINE configs[4] composition (8 subtrees, roots gathered, top [n0, n1, 0, 0]) scaled down to 8 x 2^%d leaves" % log2n)
+            W.root_hex = lambda: "".join("%016x" % (int(v) & 0xFFFFFFFFFFFFFFFF) for v in reversed(W.d_top.cpu().tolist()))
         W.step()  # allocate the context-owned level scratch outside the timed region
     elif wl == "encrypt":
         d_out = torch.empty((n, 3, 4), dtype=torch.int64, device=dev)
@@ -424,7 +513,16 @@ def make_workload(E, wl, log2n):
             ref = torch.empty(4, dtype=torch.int64, device=dev)
             ctx.merkle4_tree_device(tag, d_in, n, ref, None)
             torch.cuda.synchronize()
-            return bool(torch.equal(top, ref) and torch.equal(ref, d_out))
+            if not dist.is_initialized():
+                return bool(torch.equal(top, ref) and torch.equal(ref, d_out))
+            # sharded build: the timed step's root (d_top: through the library's ncclAllGather, or the torch exchange) must be the
+            # tree over ALL ranks' subtree roots — re-gathered here through torch.distributed, an independent exchange
+            mine = ref if E.coll_dev == dev else ref.cpu()
+            gathered = torch.empty(world * 4, dtype=torch.int64, device=E.coll_dev)
+            dist.all_gather_into_tensor(gathered, mine)
+            again = P.merkle4_tree(gathered.to(dev).view(world, 4).contiguous(), tag=tag, ctx=ctx)
+            torch.cuda.synchronize()
+            return bool(torch.equal(top, ref) and torch.equal(again, W.d_top))
         if wl == "encrypt":
             # decrypting what was just produced gives the messages back, with every authentication flag set
             back = torch.empty((n, 2, 4), dtype=torch.int64, device=dev)
@@ -507,11 +605,14 @@ def run_timed(E, W, steps, warmup):
     for i in range(steps):
         W.step()  # launched on torch's current stream; the events below are recorded on that same stream
         evs[i + 1].record()
+    E.torch.cuda.synchronize()
+    own = time.perf_counter() - t0  # this rank's own work done (before the closing barrier: the balance figure)
     E.barrier()
     elapsed = time.perf_counter() - t0
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
     clk_after = probe_under_load(E, W, step_ms_est)
     elapsed = E.max_over_ranks(elapsed)
+    W.rank_ms_per_step = [v / steps * 1e3 for v in E.per_rank(own)]
     return elapsed, launch_ms, clk_before, clk_after
 
 
@@ -574,18 +675,42 @@ def roofline_of(W, launch_ms, clk_before, clk_after, sclk_sysfs=None):
                  "frac": cyc / (SIMDS * NOMINAL_CLOCK_HZ), "frac_at_measured_clock": cyc / (SIMDS * ghz * 1e9) if ghz else None,
                  "pmc": pmc_valu(pmc_key or kern),
                  "note": "SIMD cycles spent issuing VALU work under the 4-/2-cycle model / all SIMD cycles (at 2.4 GHz; at the measured clock)"}
+    traffic = pmc_traffic(pmc_key or kern, wl, W.perms_per_step)
+    exe_frac = executed["frac"] if executed else None
     return {
+        # ---- top-level SCALARS (the driver's record keeps only these): the HARDWARE fraction first ----
+        # achieved = multiply-adds the kernel actually issues (ISA-derived count x lanes x permutations per launch / mean launch
+        # time, HIP events on the launch stream); peak = 1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes; frac = achieved / peak <= 1
         "bound": "valu-int32-mac", "kernel": kern,
-        "achieved": achieved_mac / 1e12, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
-        "frac": achieved_mac / PEAK_INT32_MAC_PER_S,
-        "note": "SURVEY §8d figure: 256,000 MACs per permutation (reference schedule) x permutations per launch / mean launch time "
-                "(HIP events on the launch stream) against the VALU issue peak.  The kernel runs an algebraically equivalent schedule with "
-                "4x fewer multiply-adds, so this exceeds 1 and says nothing about the hardware; `executed.frac` does.",
+        "achieved": executed["achieved"] if executed else None, "peak": PEAK_INT32_MAC_PER_S / 1e12, "unit": "TMAC/s",
+        "frac": exe_frac,
+        "frac_at_measured_clock": executed["frac_at_measured_clock"] if executed else None,
+        "frac_of_measured_mad_stream": executed["frac_of_measured_mad_stream"] if executed else None,
+        "frac_valu_issue": issue["frac"] if issue else None,
+        "frac_valu_issue_at_measured_clock": issue["frac_at_measured_clock"] if issue else None,
+        "macs_per_perm_executed": executed["macs_per_perm"] if executed else None,
+        "valu_insts_per_perm": issue["valu_insts_per_perm"] * lanes_per_perm if issue else None,
+        "clock_ghz_measured": ghz,
+        "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)), "units_per_launch": W.perms_per_step,
+        # HBM bytes per step from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) next to the algorithmic bytes
+        "traffic": traffic.get("bytes") if traffic else None,
+        "traffic_algorithmic_bytes": BYTES_PER_PERM[wl] * W.perms_per_step,
+        "traffic_ratio": traffic.get("ratio") if traffic else None,
+        "hbm_achieved_gbps": hbm_gbps, "hbm_frac": hbm_gbps / PEAK_HBM_GBPS,
+        # SURVEY §8d's pricing: the REFERENCE schedule's 256,000 MACs per permutation against the same peak.  The kernel runs an
+        # algebraically equivalent schedule with 4x fewer multiply-adds (bit-exact), so this is an algorithmic speed-up times a
+        # hardware fraction — it exceeds 1 and says nothing about the hardware; `frac` above does.
+        "macs_per_perm_reference_schedule": MACS_PER_PERM_REFERENCE,
+        "achieved_reference_schedule": achieved_mac / 1e12,
+        "frac_reference_schedule": achieved_mac / PEAK_INT32_MAC_PER_S,
+        "note": "frac = multiply-adds actually issued (counted in the ISA, equal to SQ_INSTS_VALU-derived counts) / VALU issue peak at the nominal "
+                "2.4 GHz; *_at_measured_clock = the same at the shader clock measured in this run; frac_valu_issue = SIMD cycles issuing any VALU "
+                "instruction (4-/2-cycle model) / all SIMD cycles; *_reference_schedule = SURVEY §8d's 256,000-MAC figure (not a hardware fraction)",
+        # ---- nested detail (sources, probes, per-model notes) ----
         "executed": executed, "valu_issue": issue, "clock": clock,
-        "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
         "hbm": {"achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS,
                 "algorithmic_bytes_per_perm": BYTES_PER_PERM[wl]},
-        "traffic": pmc_traffic(pmc_key or kern, wl, W.perms_per_step),
+        "traffic_detail": traffic,
     }
 
 
@@ -658,15 +783,21 @@ def main():
     samples = [(primary_key,) + sample] if sample else []
     line = None
     if rank == 0:
-        total_perms = W.perms_per_step * args.steps * world
+        total_perms = getattr(W, "job_units_per_step", W.perms_per_step * world) * args.steps
         roofline = roofline_of(W, launch_ms, cb, ca, {"idle_before_run": sclk0, "after_timed_region": sysfs_sclk_mhz(torch, local_rank)})
         line = {
             "metric": "Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact",
             "value": total_perms / elapsed, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3,
+            # every rank's own time per step up to its last launch completing (before the closing barrier): min / max = balance
+            "ms_per_step_rank_min": min(W.rank_ms_per_step), "ms_per_step_rank_max": max(W.rank_ms_per_step), "ms_per_step_per_rank": W.rank_ms_per_step,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "dtype_note": "255-bit field elements as 9 x 29-bit limbs (int32), products accumulated in signed 64-bit columns (v_mad_i64_i32)",
-            "config": {"workload": W.name, "units_per_gpu_per_step": W.perms_per_step, "sharding": "independent batches per GPU, no data-path collective",
+            "config": {"workload": W.name, "units_per_gpu_per_step": W.perms_per_step,
+                       "units_whole_job_per_step": getattr(W, "job_units_per_step", W.perms_per_step * world),
+                       "exchange_impl": getattr(W, "exchange_impl", None), "root_mont_hex": W.root_hex() if hasattr(W, "root_hex") else None,
+                       "sharding": "independent batches per GPU, no data-path collective",
                        "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input": "splitmix64 seed 0xc10d + rank, uniform mod p (SURVEY §8d)",
@@ -674,7 +805,7 @@ def main():
             "roofline": roofline,
             # the same kernel priced against the HBM roofline in the contract's shape (NOT the binding bound here)
             "roofline_hbm": {"bound": "hbm", "achieved": roofline["hbm"]["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": roofline["hbm"]["frac"], "traffic": roofline["traffic"]},
+                             "frac": roofline["hbm"]["frac"], "traffic": roofline["traffic"], "traffic_ratio": roofline["traffic_ratio"]},
             "self_consistency_ok": self_ok,
             "setup": {"wake_up_launches": W.wake,
                       "note": "untimed launches of the same step before the W warm-up steps: brings an idle GPU's clocks to steady state; "
@@ -698,11 +829,18 @@ def main():
             r2 = roofline_of(W2, lm2, cb2, ca2)
             secondary[key] = {
                 "workload": W2.name, "units_per_gpu_per_step": W2.perms_per_step, "steps": s_steps, "warmup": s_warm,
-                "wake_up_launches": W2.wake, "ms_per_step": el2 / s_steps * 1e3, "value": W2.perms_per_step * s_steps * world / el2,
+                "wake_up_launches": W2.wake, "ms_per_step": el2 / s_steps * 1e3,
+                "units_whole_job_per_step": getattr(W2, "job_units_per_step", W2.perms_per_step * world),
+                "value": getattr(W2, "job_units_per_step", W2.perms_per_step * world) * s_steps / el2,
+                "ms_per_step_rank_min": min(W2.rank_ms_per_step), "ms_per_step_rank_max": max(W2.rank_ms_per_step), "ms_per_step_per_rank": W2.rank_ms_per_step,
                 "unit": "permutations/s", "n_gpus": world,
                 "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                 "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                 "exchange": ("all-gather of %d x 32-byte subtree roots per step" % world) if (key == "tree" and dist.is_initialized()) else None,
+                "exchange_impl": getattr(W2, "exchange_impl", None),
+                # (Montgomery limbs of the root the last timed step left on rank 0, most significant first: the N > 1 rehearsal test
+                # compares it with the oracle tree over the concatenation of all ranks' leaves)
+                "root_mont_hex": W2.root_hex() if hasattr(W2, "root_hex") else None,
                 "roofline": r2, "self_consistency_ok": ok2, "parity_sample_ok": None,
             }
         del W2

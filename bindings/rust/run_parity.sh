@@ -7,7 +7,9 @@
 #   bash bindings/rust/run_parity.sh            # online: cargo fetches dusk-poseidon 0.42.0-rc.0, dusk-safe 0.3, ...
 #   bash bindings/rust/run_parity.sh --offline  # uses bindings/rust/vendor/ (made on a connected machine, see below)
 #
-# Output: bindings/rust/RUSTPARITY.json — {"ok": bool, "tests": {...}, "tag_inputs": {...}, "encryption": {"2": {"stream": bool,
+# Output: bindings/rust/RUSTPARITY.diff — the run against the library's PREDICTION (RUSTPARITY.expected.json: tag-input bytes and tag
+# limbs per shape, STREAM / DUPLEX verdict per length): one line per difference, so the first person to run this reads a diff, not a
+# log — and bindings/rust/RUSTPARITY.json — {"ok": bool, "tests": {...}, "tag_inputs": {...}, "encryption": {"2": {"stream": bool,
 # "duplex": bool}, ...}, "log": "RUSTPARITY.log"} — and the full cargo log beside it.  Paste the JSON into DESIGN.md §5.
 #
 # offline: on a machine WITH network access, in bindings/rust:   cargo vendor vendor > .cargo/vendor-config.toml
@@ -47,4 +49,7 @@ for m in re.finditer(r"^RUSTPARITY (\S+) (\{.*\})$", log, re.M):
 json.dump(out, open("RUSTPARITY.json", "w"), indent=1)
 print("wrote", "bindings/rust/RUSTPARITY.json:", "PASS" if out["ok"] else "FAIL", out["tests"])
 PY
+# 4. against the library's prediction (RUSTPARITY.expected.json, tools/gen_rustparity_expected.py): one line per difference —
+#    tag-input bytes, tag limbs, STREAM / DUPLEX verdict per length, test outcomes — or the statement that everything is pinned
+python3 "$ROOT/tools/gen_rustparity_expected.py" --diff RUSTPARITY.json | tee RUSTPARITY.diff
 exit $RC

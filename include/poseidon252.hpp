@@ -248,6 +248,7 @@ inline std::vector<BlsScalar> digest_multi(const std::vector<Context*>& ctxs, co
     return out;
 }
 // root of the arity-4 tree over ctxs.size() * 4^k leaves: one complete subtree per device, 32-byte roots gathered on the host
+// (host leaves: they stream in through each context's staging lanes; device-resident shards: p252_merkle4_tree_multi_device, RCCL)
 inline BlsScalar merkle4_root_multi(const std::vector<Context*>& ctxs, const std::vector<BlsScalar>& leaves) {
     if (ctxs.empty() || leaves.empty()) throw std::invalid_argument("merkle4_root_multi: bad arguments");
     std::vector<p252_ctx*> raw;
@@ -257,6 +258,59 @@ inline BlsScalar merkle4_root_multi(const std::vector<Context*>& ctxs, const std
     detail::check(p252_merkle4_tree_multi(raw.data(), raw.size(), tag.data(), leaves[0].data(), leaves.size(), root.data()), raw[0],
                   "merkle4_root_multi");
     return root;
+}
+
+// ---- RCCL communicator of the library (p252_comm_*): the constants are broadcast and validated when it is created, the
+// sharded tree build all-gathers its 32-byte subtree roots on the stream.  One Comm per Context.  One process per GPU:
+// rank 0 calls Comm::unique_id() and hands the bytes to the other ranks, every rank constructs Comm(ctx, id, rank, world).
+// One process, several GPUs: Comm::create_all(contexts on distinct devices). ----
+class Comm {
+  public:
+    using Id = std::array<unsigned char, P252_COMM_ID_BYTES>;
+    static Id unique_id() {
+        Id id{};
+        detail::check(p252_comm_unique_id(id.data(), id.size()), nullptr, "p252_comm_unique_id");
+        return id;
+    }
+    Comm(Context& ctx, const Id& id, int rank, int world) : ctx_(ctx) {
+        p252_comm* c = nullptr;
+        detail::check(p252_comm_create_rank(ctx.get(), id.data(), id.size(), rank, world, &c), ctx.get(), "p252_comm_create_rank");
+        comm_.reset(c, p252_comm_destroy);
+    }
+    static std::vector<Comm> create_all(const std::vector<Context*>& ctxs) {
+        if (ctxs.empty()) throw std::invalid_argument("Comm::create_all: no contexts");
+        std::vector<p252_ctx*> raw;
+        for (Context* c : ctxs) raw.push_back(c->get());
+        std::vector<p252_comm*> out(raw.size(), nullptr);
+        detail::check(p252_comm_create_all(raw.data(), raw.size(), out.data()), raw[0], "p252_comm_create_all");
+        std::vector<Comm> v;
+        for (std::size_t t = 0; t < raw.size(); ++t) v.push_back(Comm(*ctxs[t], out[t]));
+        return v;
+    }
+    int rank() const { return p252_comm_rank(comm_.get()); }
+    int size() const { return p252_comm_size(comm_.get()); }
+    // this rank's 4^k device-resident leaves -> root over ALL ranks' leaves in d_root (32 B, device), asynchronously on
+    // `stream`; collective (every rank calls it)
+    void merkle4_root_sharded_device(const void* d_leaves, std::size_t n_leaves_local, void* d_root, void* stream = nullptr) {
+        const BlsScalar tag = compute_tag(Domain::Merkle4, {4}, 1);
+        detail::check(p252_merkle4_tree_sharded_device(comm_.get(), tag.data(), d_leaves, n_leaves_local, d_root, stream), ctx_.get(),
+                      "merkle4_root_sharded_device");
+    }
+    p252_comm* get() const { return comm_.get(); }
+
+  private:
+    Comm(Context& ctx, p252_comm* c) : ctx_(ctx) { comm_.reset(c, p252_comm_destroy); }
+    Context ctx_;  // (shared ownership: the context outlives its communicator)
+    std::shared_ptr<p252_comm> comm_;
+};
+
+// A forest of roots.size() independent complete trees of leaves_per_tree = 4^k device-resident leaves each (tree-major):
+// one launch per level across all trees (p252_merkle4_forest_device); d_roots receives n_trees scalars.
+inline void merkle4_forest_device(const void* d_leaves, std::size_t n_trees, std::size_t leaves_per_tree, void* d_roots,
+                                  Context& ctx = Context::default_context(), void* d_levels = nullptr, void* stream = nullptr) {
+    const BlsScalar tag = compute_tag(Domain::Merkle4, {4}, 1);
+    detail::check(p252_merkle4_forest_device(ctx.get(), tag.data(), d_leaves, n_trees, leaves_per_tree, d_roots, d_levels, stream), ctx.get(),
+                  "merkle4_forest_device");
 }
 
 // ---- dusk_poseidon::encrypt / decrypt (src/encryption.rs:62-95), batched; `variant` = P252_CRYPT_STREAM (default) or

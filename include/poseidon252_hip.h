@@ -54,8 +54,11 @@ extern "C" {
  *      of every wrapper is P252_CRYPT_STREAM (version 0.2 of the library had no selector and computed P252_CRYPT_DUPLEX:
  *      ciphertexts of messages longer than 4 scalars made then decrypt only with variant = P252_CRYPT_DUPLEX)
  *   5  + p252_abi_version, p252_merkle4_update_checked_device, p252_clock_probe_device, p252_staging_lanes; out-of-range
- *      indices of p252_merkle4_update_device are skipped (were undefined behaviour) */
-#define P252_ABI_VERSION 5
+ *      indices of p252_merkle4_update_device are skipped (were undefined behaviour)
+ *   6  + the RCCL communicator (p252_comm_*), p252_merkle4_tree_sharded_device, p252_merkle4_tree_multi_device_resident,
+ *      p252_merkle4_forest_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
+ *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on) */
+#define P252_ABI_VERSION 6
 
 #define P252_OK 0
 #define P252_ERR_IO_PATTERN_VIOLATION (-1) /* dusk_poseidon::Error::IOPatternViolation, src/error.rs:12-14 */
@@ -63,6 +66,7 @@ extern "C" {
 #define P252_ERR_INVALID_ARGUMENT (-3)
 #define P252_ERR_HIP (-4)
 #define P252_ERR_NO_DEVICE (-5)
+#define P252_ERR_COMM (-6) /* an RCCL call failed (communicator creation, broadcast of the constants, all-gather of the roots) */
 
 /* Domain discriminants, in the declaration order of `enum Domain` (src/hash.rs:21-36) */
 #define P252_DOMAIN_MERKLE4 0
@@ -73,6 +77,8 @@ extern "C" {
 #define P252_HADES_WIDTH 5 /* dusk_poseidon::HADES_WIDTH, src/lib.rs:17 */
 
 typedef struct p252_ctx p252_ctx;
+typedef struct p252_comm p252_comm; /* one rank of an RCCL communicator, bound to one context (multi-GPU section below) */
+#define P252_COMM_ID_BYTES 128      /* size of the opaque id p252_comm_unique_id produces (= RCCL's ncclUniqueId) */
 
 /* ---- lifecycle ---- */
 int p252_device_count(void);
@@ -204,6 +210,17 @@ int p252_encrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
 int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
                               const void* d_nonces, size_t len, void* d_messages, void* d_ok, size_t n, void* hip_stream);
 
+/* A FOREST of n_trees independent complete arity-4 trees of leaves_per_tree = 4^k leaves each (the downstream poseidon-merkle
+ * shape, AGENTS.md:62-66: many small trees), tree-major in d_leaves.  Level l of all trees is one array of
+ * n_trees * 4^(k-l) nodes, tree-major, and each level is ONE launch across all trees — the narrow upper levels of many small
+ * trees fill the chip together instead of each tree paying one wave's latency per level (k launches instead of
+ * n_trees * k).  d_roots[n_trees] (device) receives tree t's root at index t: identical to p252_merkle4_tree_device of
+ * that tree alone.  d_levels (device, may be NULL): all levels bottom-up, level-major —
+ * n_trees * p252_merkle4_levels_len(leaves_per_tree) scalars, level l at offset n_trees * (4^(k-1) + ... + 4^(k-l+1)),
+ * tree t's nodes of that level at t * 4^(k-l) within it.  Asynchronous on hip_stream. */
+int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
+                               void* d_roots, void* d_levels, void* hip_stream);
+
 /* ---- multi-device: an array of contexts, one per GPU.  Shards are contiguous and independent: no
  * inter-GPU dependence and no collective on the data path.  The calls are synchronous; inside, one host thread drives
  * each context.  A context may appear only once, and when the node has at least n_ctx devices no two contexts may be bound
@@ -224,9 +241,42 @@ int p252_hash_batch_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const uint
  * n_leaves = n_ctx * 4^k -> P252_ERR_INVALID_ARGUMENT. */
 int p252_merkle4_tree_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
                             uint64_t root[4]);
-/* the same with every device's leaves_per_ctx = 4^k leaves already resident at d_leaves[t]; root is written to host memory */
+/* the same with every device's leaves_per_ctx = 4^k leaves already resident at d_leaves[t]; root is written to host memory.
+ * Contexts on distinct devices: the roots are exchanged by ONE ncclAllGather on the devices' streams (the RCCL communicator
+ * over the contexts is created on the first such call — or beforehand with p252_comm_create_all — and kept; it is destroyed
+ * with its contexts) and every device hashes the top levels, so nothing but the final 32 bytes crosses PCIe.  Contexts
+ * that share a device (RCCL wants one device per rank: the single-GPU test configuration), or P252_MULTI_HOST_GATHER=1:
+ * the roots are gathered through the host and the top levels run on ctxs[0]. */
 int p252_merkle4_tree_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,
                                    size_t leaves_per_ctx, uint64_t root[4]);
+/* the RCCL path only, fully asynchronous and device-resident: on return the work is queued on hip_streams[t] (NULL: the
+ * default streams) and d_root_out[t] (32 bytes on ctxs[t]'s device; entries, or the array, may be NULL) will hold the
+ * root on EVERY device — no host round trip.  P252_ERR_COMM when the contexts cannot form a communicator. */
+int p252_merkle4_tree_multi_device_resident(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,
+                                            size_t leaves_per_ctx, void* const* d_root_out, void* const* hip_streams);
+
+/* ---- RCCL communicator (BASELINE north_star: "RCCL broadcast of constants", "RCCL gather of roots").  The path
+ * has no data-path collective; a communicator exists for (i) the constant table: on creation rank 0's table is broadcast
+ * (ncclBroadcast) and every rank REFUSES it unless it equals the table it derives from its own arc.bin / mds.bin — the rule
+ * of p252_tables_import — and (ii) the 32-byte subtree roots of a sharded tree build (ncclAllGather on the rank's stream).
+ * One process per GPU: rank 0 calls p252_comm_unique_id and passes the bytes to the other ranks by any host means; every
+ * rank calls p252_comm_create_rank with its own context (collective: returns when all `world` ranks have called).
+ * One process, several GPUs: p252_comm_create_all over contexts on DISTINCT devices.  A context belongs to at most one
+ * communicator; destroy the communicator before its context.  xGMI note: these messages are world x 32 bytes — latency
+ * only. ---- */
+int p252_comm_unique_id(void* id_out, size_t len /* = P252_COMM_ID_BYTES */);
+int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, int world, p252_comm** out);
+int p252_comm_create_all(p252_ctx* const* ctxs, size_t n_ctx, p252_comm** comms_out /* [n_ctx] */);
+void p252_comm_destroy(p252_comm* comm);
+int p252_comm_rank(const p252_comm* comm);
+int p252_comm_size(const p252_comm* comm);
+/* BASELINE configs[4], one rank's part (one process per GPU): this rank's n_leaves_local = 4^k device-resident leaves are
+ * reduced to their root with zero communication, the `world` roots are all-gathered (the path's only exchange step, on
+ * hip_stream) and the <= log4(world) + 1 top levels (zero-padded per hash.rs:22-26) are hashed on every rank: d_root
+ * (32 bytes, device) = the root of the tree over the concatenation of all ranks' leaves, in rank order, on every rank.
+ * Asynchronous on hip_stream; collective: every rank of the communicator must call it. */
+int p252_merkle4_tree_sharded_device(p252_comm* comm, const uint64_t tag[4], const void* d_leaves, size_t n_leaves_local, void* d_root,
+                                     void* hip_stream);
 
 /* ---- constant-table exchange (multi-GPU: rank 0 broadcasts its derived table over RCCL, every
  * rank imports it; byte-identical to what p252_create derives locally) ---- */

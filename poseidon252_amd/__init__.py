@@ -6,9 +6,9 @@ Nothing in this package imports oracle/ or computes hashes on the CPU.
 """
 from .hash import (Context, DeviceError, Domain, Error, Hash, HashBatch, HADES_WIDTH, InvalidIOPattern,
                    IOPatternViolation, check_io_pattern, compute_tag, from_bytes, to_bytes, truncate250)
-from .merkle import merkle4_tree, merkle4_tag, levels_len
+from .merkle import merkle4_tree, merkle4_forest, merkle4_tag, levels_len
 from .encryption import DecryptionFailed, decrypt, decrypt_batch, encrypt, encrypt_batch, encryption_tag
 
 __all__ = ["Context", "DeviceError", "Domain", "Error", "Hash", "HashBatch", "HADES_WIDTH", "InvalidIOPattern",
            "IOPatternViolation", "check_io_pattern", "compute_tag", "truncate250", "from_bytes", "to_bytes", "merkle4_tree", "merkle4_tag",
-           "levels_len"]
+           "levels_len", "merkle4_forest"]

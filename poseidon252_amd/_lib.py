@@ -16,6 +16,8 @@ ERR_INVALID_IO_PATTERN = -2
 ERR_INVALID_ARGUMENT = -3
 ERR_HIP = -4
 ERR_NO_DEVICE = -5
+ERR_COMM = -6
+COMM_ID_BYTES = 128
 
 # every symbol include/poseidon252_hip.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
@@ -31,8 +33,10 @@ ABI_SYMBOLS = (
     "p252_to_bytes_device", "p252_from_bytes_device", "p252_to_bytes", "p252_from_bytes", "p252_merkle4_update_device",
     "p252_domain_separator", "p252_check_io_pattern", "p252_tag", "p252_truncate250", "p252_version",
     "p252_abi_version", "p252_merkle4_update_checked_device", "p252_clock_probe_device", "p252_staging_lanes",
+    "p252_comm_unique_id", "p252_comm_create_rank", "p252_comm_create_all", "p252_comm_destroy", "p252_comm_rank", "p252_comm_size",
+    "p252_merkle4_tree_sharded_device", "p252_merkle4_tree_multi_device_resident", "p252_merkle4_forest_device",
 )
-ABI_VERSION = 5  # include/poseidon252_hip.h P252_ABI_VERSION this binding was written against
+ABI_VERSION = 6  # include/poseidon252_hip.h P252_ABI_VERSION this binding was written against
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _szp = ctypes.POINTER(ctypes.c_size_t)
@@ -70,6 +74,13 @@ def _preload_torch_hip_runtime():
         ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     except OSError:
         return None
+    # the same for RCCL (the library links librccl.so.1 since ABI 6; torch bundles a copy under that SONAME): one copy per process
+    rccl = os.path.join(os.path.dirname(path), "librccl.so")
+    if os.path.exists(rccl):
+        try:
+            ctypes.CDLL(rccl, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
     return path
 
 
@@ -83,6 +94,18 @@ def lib():
             "(hipcc --offload-arch=gfx950).  poseidon252_amd has no CPU fallback." % LIB_PATH)
     _preload_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
+    if not os.environ.get("P252_LIB_PATH"):
+        # FIRST thing after loading: argument lists changed between versions under unchanged names, and a stale
+        # build (*.so is git-ignored, so it survives a checkout) lacks the newer symbols — setting their argtypes below would
+        # raise a raw "undefined symbol" AttributeError before any version check could speak
+        if hasattr(L, "p252_abi_version"):
+            L.p252_abi_version.restype = ctypes.c_int
+            have = L.p252_abi_version()
+        else:
+            have = None
+        if have != ABI_VERSION:
+            raise ExtensionMissing("%s implements ABI version %s, this binding needs %d: rebuild it (python -m poseidon252_amd.build)"
+                                   % (LIB_PATH, have, ABI_VERSION))
     if os.environ.get("P252_LIB_PATH"):
         # developer A/B switch only: an OLDER build of the library may lack entry points added since; give those a stub
         # that fails loudly when called, so that the benchmarks of the entry points it does have can still be compared
@@ -159,17 +182,17 @@ def lib():
     L.p252_merkle4_update_checked_device.argtypes = [_vp, _u64p, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp]
     L.p252_clock_probe_device.argtypes = [_vp, _vp, ctypes.c_uint, _vp]
     L.p252_staging_lanes.argtypes = [_sz]
+    L.p252_comm_unique_id.argtypes = [_vp, _sz]
+    L.p252_comm_create_rank.argtypes = [_vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]
+    L.p252_comm_create_all.argtypes = [_vpp, _sz, _vpp]
+    L.p252_comm_destroy.argtypes = [_vp]
+    L.p252_comm_destroy.restype = None
+    L.p252_comm_rank.argtypes = [_vp]
+    L.p252_comm_size.argtypes = [_vp]
+    L.p252_merkle4_tree_sharded_device.argtypes = [_vp, _u64p, _vp, _sz, _vp, _vp]
+    L.p252_merkle4_tree_multi_device_resident.argtypes = [_vpp, _sz, _u64p, _vpp, _sz, _vpp, _vpp]
+    L.p252_merkle4_forest_device.argtypes = [_vp, _u64p, _vp, _sz, _sz, _vp, _vp, _vp]
     L.p252_abi_version.restype = ctypes.c_int
-    if not os.environ.get("P252_LIB_PATH"):
-        # argument lists changed between versions under unchanged names: never call into a library whose
-        # interface is not the one these argtypes describe
-        try:
-            have = L.p252_abi_version()
-        except AttributeError:
-            have = None
-        if have != ABI_VERSION:
-            raise ExtensionMissing("%s implements ABI version %s, this binding needs %d: rebuild it (python -m poseidon252_amd.build)"
-                                   % (LIB_PATH, have, ABI_VERSION))
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("p252_device_count",):

@@ -15,8 +15,10 @@ HIPCC_FLAGS = [
     # silently turns them into scratch-indexed loops
     "-mllvm", "-pragma-unroll-threshold=1000000",
 ]
-SOURCES = ["kernels.hip", "api.cpp"]
-HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp",
+SOURCES = ["kernels.hip", "api.cpp", "comm.cpp"]
+# comm.cpp: the RCCL communicator of the multi-GPU entry points (ncclBroadcast of the constants, ncclAllGather of subtree roots)
+LINK_FLAGS = ["-L/opt/rocm/lib", "-lrccl"]
+HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp", "ctx.hpp",
            os.path.join("..", "..", "include", "poseidon252_hip.h")]
 
 
@@ -41,10 +43,24 @@ def _stale(target, deps):
 
 
 def build_library(force=False, verbose=False):
+    """every source to its own object (only what changed is recompiled: kernels.hip takes ~50 s, the host files seconds),
+    then one link.  Objects live in csrc/_gen/obj (git-ignored)."""
     _gen_assets()
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(CSRC, "_gen", "assets.inc")]
-    if force or _stale(LIB, deps):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    hdeps = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(CSRC, "_gen", "assets.inc"), os.path.abspath(__file__)]
+    objdir = os.path.join(CSRC, "_gen", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs, relink = [], force or not os.path.exists(LIB)
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        if force or _stale(obj, [os.path.join(CSRC, src)] + hdeps):
+            cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+            relink = True
+        objs.append(obj)
+    if relink or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + LINK_FLAGS + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

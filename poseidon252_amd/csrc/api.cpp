@@ -15,54 +15,19 @@
 
 #include "../../include/poseidon252_hip.h"
 #include "blake2b.hpp"
+#include "ctx.hpp"
 #include "hades29.hpp"
 #include "kernels.h"
 #include "tables.hpp"
 #include "_gen/assets.inc"
 
 using namespace p252;
-
-struct p252_ctx {
-    int device = -1;
-    int32_t* d_tab = nullptr;
-    std::vector<int32_t> h_tab;
-    // grow-only scratch for the host-buffer entry points and the tree builder
-    void* d_in = nullptr;
-    size_t d_in_cap = 0;
-    void* d_out = nullptr;
-    size_t d_out_cap = 0;
-    void* d_lvl[2] = {nullptr, nullptr};
-    size_t d_lvl_cap[2] = {0, 0};
-    hipStream_t streams[3] = {nullptr, nullptr, nullptr};  // host-buffer pipeline over caller-pinned memory (created on first use)
-    // host-buffer pipeline over PAGEABLE caller memory: library-owned page-locked staging, one lane per worker thread
-    // (stream + pinned in/out chunk + device in/out chunk), created on first use and kept
-    struct Slot {  // one chunk in flight: page-locked staging pair, device pair, completion event
-        void* h_in = nullptr;
-        void* h_out = nullptr;
-        void* d_in = nullptr;
-        void* d_out = nullptr;
-        size_t in_cap = 0, out_cap = 0;
-        hipEvent_t done = nullptr;
-    };
-    struct Lane {  // one worker thread + stream, double-buffered: the host copy of chunk c+1 overlaps the DMA / kernel of chunk c
-        hipStream_t st = nullptr;
-        Slot slot[2];
-    };
-    std::vector<Lane> lanes;
-    int lane_budget = 0;  // > 0: staging lanes this call may use (set by the p252_*_multi drivers, which share the CPU quota)
-    // encryption: the sponge-call program of the last (variant, message_len) used, uploaded once (k_crypt interprets it)
-    uint32_t* d_prog = nullptr;
-    size_t d_prog_cap = 0;
-    int prog_variant = -1;
-    size_t prog_len = 0;
-    unsigned prog_calls = 0;
-    std::string err;
-};
+using namespace p252host;
 
 static std::string g_create_err;
 static std::mutex g_mu;
 
-static int fail(p252_ctx* ctx, int code, const std::string& msg) {
+int p252host::fail(p252_ctx* ctx, int code, const std::string& msg) {
     if (ctx)
         ctx->err = msg;
     else {
@@ -72,14 +37,7 @@ static int fail(p252_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
-#define HIP_TRY(ctx, expr)                                                                  \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(ctx, P252_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-static int ensure(p252_ctx* ctx, void** buf, size_t* cap, size_t need) {
+int p252host::ensure(p252_ctx* ctx, void** buf, size_t* cap, size_t need) {
     if (need <= *cap) return P252_OK;
     if (*buf) HIP_TRY(ctx, hipFree(*buf));
     *buf = nullptr;
@@ -89,7 +47,7 @@ static int ensure(p252_ctx* ctx, void** buf, size_t* cap, size_t need) {
     return P252_OK;
 }
 
-static const std::vector<int32_t>& host_tables() {
+const std::vector<int32_t>& p252host::host_tables() {
     static const std::vector<int32_t> tab = [] {
         HadesTables T;
         derive_tables(ARC_BIN, MDS_BIN, T);
@@ -133,7 +91,7 @@ extern "C" {
 
 int p252_abi_version(void) { return P252_ABI_VERSION; }
 
-const char* p252_version(void) { return "poseidon252_hip 0.5 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
+const char* p252_version(void) { return "poseidon252_hip 0.6 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
 
 int p252_device_count(void) {
     int n = 0;
@@ -173,6 +131,7 @@ int p252_create(int device_id, p252_ctx** out) {
 
 void p252_destroy(p252_ctx* ctx) {
     if (!ctx) return;
+    release_ctx_comm(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
@@ -254,7 +213,8 @@ static size_t levels_len(size_t n_leaves, size_t arity) {
 size_t p252_merkle4_levels_len(size_t n_leaves) { return levels_len(n_leaves, 4); }
 size_t p252_merkle2_levels_len(size_t n_leaves) { return levels_len(n_leaves, 2); }
 
-static int merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
+extern "C++" {
+int p252host::merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
                               void* d_root, void* d_levels, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (n_leaves == 0) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree: n_leaves must be > 0");
@@ -296,10 +256,58 @@ static int merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[
     HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
     return P252_OK;
 }
+}  // extern "C++"
 
 int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
                              void* d_root, void* d_levels, void* hip_stream) {
     return merkle_tree_device(ctx, 4, tag, d_leaves, n_leaves, d_root, d_levels, hip_stream);
+}
+
+// A forest of n_trees independent complete arity-4 trees of leaves_per_tree = 4^k leaves each, tree-major in d_leaves
+// (the shape of the downstream poseidon-merkle consumers, AGENTS.md:62-66: many small trees).  Level l of ALL trees is one
+// array of n_trees * 4^(k-l) nodes, tree-major — so the forest is the first k levels of the level-by-level reduction of
+// the concatenated leaves, and each level is ONE launch across all trees: the narrow upper levels of many small trees
+// fill the chip together instead of each paying one wave's latency per tree.
+int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
+                               void* d_roots, void* d_levels, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n_trees == 0) return P252_OK;
+    if (!power_of_4(leaves_per_tree)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_forest: leaves_per_tree must be 4^k");
+    if (n_trees > (SIZE_MAX / 32) / leaves_per_tree) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_forest: size overflow");
+    if (!tag || !d_leaves || !d_roots) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_forest: NULL buffer");
+    if (misaligned(d_leaves) || misaligned(d_roots) || misaligned(d_levels)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    size_t cur_n = n_trees * leaves_per_tree;
+    if (leaves_per_tree == 1) {  // a single leaf is its own root (as in p252_merkle4_tree_device)
+        HIP_TRY(ctx, hipMemcpyAsync(d_roots, d_leaves, cur_n * 32, hipMemcpyDeviceToDevice, st));
+        return P252_OK;
+    }
+    if (!d_levels) {  // ping-pong in context-owned scratch (the last level goes straight to d_roots)
+        int rc = ensure(ctx, &ctx->d_lvl[0], &ctx->d_lvl_cap[0], cur_n / 4 * 32);
+        if (rc) return rc;
+        rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], cur_n / 16 * 32 + 32);
+        if (rc) return rc;
+    }
+    const TagArg t = tag_arg(tag);
+    const char* cur = static_cast<const char*>(d_leaves);
+    char* lv = static_cast<char*>(d_levels);
+    // narrow levels after wide ones are computed redundantly on every SIMD, as in the tree builder (clock dip)
+    const size_t pad = cur_n / 4 > 65536 ? 65536 : 0;
+    int parity = 0;
+    while (cur_n > n_trees) {
+        const size_t next_n = cur_n / 4;
+        char* next = next_n == n_trees ? static_cast<char*>(d_roots) : (d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]));
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, 4, pad));
+        if (d_levels) {
+            if (next_n == n_trees) HIP_TRY(ctx, hipMemcpyAsync(lv, d_roots, next_n * 32, hipMemcpyDeviceToDevice, st));  // levels hold the roots too
+            lv += next_n * 32;
+        }
+        cur = next;
+        cur_n = next_n;
+        parity ^= 1;
+    }
+    return P252_OK;
 }
 
 int p252_merkle2_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
@@ -333,8 +341,8 @@ struct HostSpan {  // one per-item array of a batched call: item i occupies byte
     size_t stride;
 };
 
-// CPUs this process may actually use: min(affinity mask, cgroup v2 quota).  The benchmark box shows 256 logical CPUs and
-// grants 16.
+// CPUs this process may actually use: min(affinity mask, cgroup quota — v2 cpu.max, else v1 cfs_quota_us / cfs_period_us,
+// as bench.py's usable_cpus() reads them).  The benchmark box shows 256 logical CPUs and grants 16.
 static double cpu_budget() {
     static const double cpus = [] {
         double c = (double)std::thread::hardware_concurrency();
@@ -348,6 +356,17 @@ static double cpu_budget() {
                 if (quota > 0 && quota < c) c = quota;
             }
             std::fclose(f);
+        } else {  // cgroup v1: quota in microseconds per period, -1 = unlimited
+            double quota = -1, period = 0;
+            if (FILE* fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (std::fscanf(fq, "%lf", &quota) != 1) quota = -1;
+                std::fclose(fq);
+            }
+            if (FILE* fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(fp, "%lf", &period) != 1) period = 0;
+                std::fclose(fp);
+            }
+            if (quota > 0 && period > 0 && quota / period < c) c = quota / period;
         }
         return c < 1 ? 1.0 : c;
     }();
@@ -1027,14 +1046,17 @@ int p252_encryption_tag(int variant, size_t message_len, uint64_t tag_out[4]) {
 // independent — no inter-GPU dependence, no collective on the data path; the only exchange of the sharded tree is the
 // 32-byte subtree root of every device, gathered by the host.  One host thread per context for the duration of the call.
 // ------------------------------------------------------------------------------------------
-static bool power_of_4(size_t v) {
+extern "C++" {
+bool p252host::power_of_4(size_t v) {
     if (v == 0 || (v & (v - 1))) return false;
     int tz = 0;
     while (!((v >> tz) & 1)) ++tz;
     return (tz & 1) == 0;
 }
+}  // extern "C++"
 
-static int check_ctxs(p252_ctx* const* ctxs, size_t n_ctx) {
+extern "C++" {
+int p252host::check_ctxs(p252_ctx* const* ctxs, size_t n_ctx) {
     if (!ctxs || n_ctx == 0) return P252_ERR_INVALID_ARGUMENT;
     for (size_t t = 0; t < n_ctx; ++t)
         if (!ctxs[t]) return P252_ERR_INVALID_ARGUMENT;
@@ -1056,6 +1078,7 @@ static int check_ctxs(p252_ctx* const* ctxs, size_t n_ctx) {
                                 "multi: contexts " + std::to_string(a) + " and " + std::to_string(b) + " are bound to the same device although the node has one per context");
     return P252_OK;
 }
+}  // extern "C++"
 
 // for the duration of one multi call every context works within its share of the CPU budget
 struct LaneBudgetScope {
@@ -1132,7 +1155,34 @@ int p252_merkle4_tree_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const ui
     if (!tag || !d_leaves || !root) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi_device: NULL buffer");
     if (!power_of_4(leaves_per_ctx))
         return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi_device: every device must own a complete subtree (4^k leaves)");
-    // every device reduces its resident subtree (asynchronous launches on its own default stream) ...
+    // RCCL path (contexts on distinct devices; the communicator is created on first use and kept): subtrees, ONE grouped
+    // ncclAllGather of the 32-byte roots on the devices' streams, top levels on every device — the root is device-resident
+    // everywhere and only its 32 bytes come back to the host, from ctxs[0]
+    bool used_rccl = false;
+    std::vector<void*> d_top(n_ctx, nullptr);
+    for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) {
+        p252_ctx* c = ctxs[t];
+        if (hipSetDevice(c->device) != hipSuccess) { rc = fail(c, P252_ERR_HIP, "hipSetDevice"); break; }
+        rc = ensure(c, &c->d_out, &c->d_out_cap, 32);
+        d_top[t] = c->d_out;
+    }
+    if (rc == P252_OK) rc = tree_multi_device_rccl(ctxs, n_ctx, tag, d_leaves, leaves_per_ctx, d_top.data(), nullptr, &used_rccl);
+    if (rc) {
+        if (ctxs[0]->err.empty()) ctxs[0]->err = "merkle_tree_multi_device failed on another context";
+        return rc;
+    }
+    if (used_rccl) {
+        for (size_t t = 1; t < n_ctx; ++t) {  // the call is synchronous: every device has its copy of the root when it returns
+            HIP_TRY(ctxs[t], hipSetDevice(ctxs[t]->device));
+            HIP_TRY(ctxs[t], hipStreamSynchronize(nullptr));
+        }
+        HIP_TRY(ctxs[0], hipSetDevice(ctxs[0]->device));
+        HIP_TRY(ctxs[0], hipMemcpy(root, d_top[0], 32, hipMemcpyDeviceToHost));
+        return P252_OK;
+    }
+    // HOST-GATHER path — only when the contexts share a device (RCCL wants one device per rank: the single-GPU test
+    // configuration) or P252_MULTI_HOST_GATHER=1: every device reduces its resident subtree (asynchronous launches on its
+    // own default stream) ...
     std::vector<void*> d_roots(n_ctx, nullptr);
     for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) {
         p252_ctx* c = ctxs[t];

@@ -1,0 +1,332 @@
+// comm.cpp — RCCL inside the library (north_star: "RCCL broadcast of constants over xGMI", "RCCL gather
+// of roots").  The hashing path has no data-path collective: digests and complete subtrees are independent.  What is
+// exchanged is (i) the constant table, once, when a communicator is created — broadcast from rank 0 and VALIDATED against
+// the table every rank derives itself, exactly as p252_tables_import validates — and (ii) the 32-byte subtree root of every
+// rank in the sharded tree build: ONE ncclAllGather on the rank's stream, between the subtree's last launch and the top
+// levels' first, so that the root lands device-resident on every GPU with no host round trip.
+//
+// Two ways to make a communicator, for the two ways the reference's callers would drive several GPUs:
+//   p252_comm_create_rank   one process (or thread) per GPU: rank 0 calls p252_comm_unique_id, hands the 128 bytes to the
+//                           others by whatever means the host program has (an env store, MPI, torch.distributed, a file),
+//                           every rank calls create_rank with its own context             -> ncclCommInitRank
+//   p252_comm_create_all    one process, an array of contexts on distinct devices        -> ncclCommInitAll
+// The p252_*_multi_device entry points create the second kind themselves on first use.
+//
+// xGMI is point-to-point and these messages are 32 bytes x world: the exchange is pure latency (a few microseconds), never
+// bandwidth; there is nothing to bucket or overlap.  It is on the stream so that the HOST never waits for it.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ctx.hpp"
+
+using namespace p252host;
+
+static_assert(P252_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "P252_COMM_ID_BYTES must be RCCL's unique-id size");
+
+struct p252_comm {
+    ncclComm_t nccl = nullptr;
+    p252_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    void* d_sub = nullptr;    // this rank's subtree root (32 B)
+    void* d_roots = nullptr;  // world x 32 B: the gathered roots, in rank order
+    void* d_top = nullptr;    // 32 B: the root over the gathered roots (when the caller passes no output pointer)
+    // communicators of one p252_comm_create_all share this list (rank order): collectives issued for all of them by one
+    // host thread go inside one ncclGroupStart / ncclGroupEnd
+    std::shared_ptr<std::vector<p252_comm*>> clique;
+    bool owned_by_ctx = false;  // created lazily by a p252_*_multi_device call: destroyed with its context
+};
+
+#define NCCL_TRY(ctx, expr)                                                                         \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess)                                                                      \
+            return fail(ctx, P252_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));   \
+    } while (0)
+
+namespace {
+
+int alloc_buffers(p252_comm* c) {
+    p252_ctx* ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(&c->d_sub, 32));
+    HIP_TRY(ctx, hipMalloc(&c->d_roots, (size_t)c->world * 32));
+    HIP_TRY(ctx, hipMalloc(&c->d_top, 32));
+    return P252_OK;
+}
+
+void free_comm(p252_comm* c, bool abort) {
+    if (!c) return;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->nccl) (void)(abort ? ncclCommAbort(c->nccl) : ncclCommDestroy(c->nccl));
+    if (c->d_sub) (void)hipFree(c->d_sub);
+    if (c->d_roots) (void)hipFree(c->d_roots);
+    if (c->d_top) (void)hipFree(c->d_top);
+    if (c->ctx && c->ctx->comm == c) c->ctx->comm = nullptr;
+    if (c->clique)
+        for (auto& p : *c->clique)
+            if (p == c) p = nullptr;
+    delete c;
+}
+
+// the constant table of rank `root`, broadcast over RCCL into a scratch buffer on every rank of `comms` (all of them
+// driven by this thread: one group), compared with the table this library derives from its own arc.bin / mds.bin, then
+// installed.  A mismatch is a corrupted or mismatched broadcast (another build of the library on another rank): refused.
+int broadcast_and_validate(const std::vector<p252_comm*>& comms, int root) {
+    const std::vector<int32_t>& ref = host_tables();
+    const size_t bytes = ref.size() * sizeof(int32_t);
+    std::vector<void*> scratch(comms.size(), nullptr);
+    int rc = P252_OK;
+    for (size_t t = 0; t < comms.size() && rc == P252_OK; ++t) {
+        p252_ctx* ctx = comms[t]->ctx;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&scratch[t], bytes) != hipSuccess)
+            rc = fail(ctx, P252_ERR_HIP, "comm: scratch allocation for the constant broadcast failed");
+    }
+    if (rc == P252_OK) {
+        ncclResult_t r = ncclGroupStart();
+        for (size_t t = 0; t < comms.size() && r == ncclSuccess; ++t) {
+            p252_ctx* ctx = comms[t]->ctx;
+            (void)hipSetDevice(ctx->device);
+            r = ncclBroadcast(ctx->d_tab, scratch[t], bytes, ncclUint8, root, comms[t]->nccl, nullptr);
+        }
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclBroadcast of the constant table: ") + ncclGetErrorString(r));
+    }
+    std::vector<int32_t> got(ref.size());
+    for (size_t t = 0; t < comms.size() && rc == P252_OK; ++t) {
+        p252_ctx* ctx = comms[t]->ctx;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipMemcpy(got.data(), scratch[t], bytes, hipMemcpyDeviceToHost) != hipSuccess) {  // (synchronises the null stream)
+            rc = fail(ctx, P252_ERR_HIP, "comm: reading back the broadcast constant table failed");
+        } else if (std::memcmp(got.data(), ref.data(), bytes) != 0) {
+            rc = fail(ctx, P252_ERR_INVALID_ARGUMENT,
+                      "comm: the constant table broadcast by rank " + std::to_string(root) + " differs from the one this library derives from its arc.bin / mds.bin");
+        } else if (hipMemcpy(ctx->d_tab, scratch[t], bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+            rc = fail(ctx, P252_ERR_HIP, "comm: installing the broadcast constant table failed");
+        }
+    }
+    for (size_t t = 0; t < comms.size(); ++t)
+        if (scratch[t]) {
+            (void)hipSetDevice(comms[t]->ctx->device);
+            (void)hipFree(scratch[t]);
+        }
+    if (rc != P252_OK && comms[0]->ctx->err.empty()) comms[0]->ctx->err = "comm: constant broadcast failed on another rank";
+    return rc;
+}
+
+}  // namespace
+
+namespace p252host {
+
+// called by p252_destroy: a communicator the library created for this context goes with it
+void release_ctx_comm(p252_ctx* ctx) {
+    if (ctx && ctx->comm) {
+        if (ctx->comm->owned_by_ctx)
+            free_comm(ctx->comm, false);
+        else
+            ctx->comm->ctx = nullptr, ctx->comm = nullptr;  // the caller's: it outlives the context only as a husk to destroy
+    }
+}
+
+// the communicators of `ctxs` (rank t = ctxs[t]) when they all belong to ONE clique in exactly this order, else empty
+static std::vector<p252_comm*> clique_of(p252_ctx* const* ctxs, size_t n_ctx) {
+    std::vector<p252_comm*> v;
+    if (!ctxs[0]->comm || !ctxs[0]->comm->clique || ctxs[0]->comm->clique->size() != n_ctx) return v;
+    const auto& cl = *ctxs[0]->comm->clique;
+    for (size_t t = 0; t < n_ctx; ++t)
+        if (!cl[t] || cl[t]->ctx != ctxs[t] || ctxs[t]->comm != cl[t] || cl[t]->rank != (int)t) return v;
+    v.assign(cl.begin(), cl.end());
+    return v;
+}
+
+static bool distinct_devices(p252_ctx* const* ctxs, size_t n_ctx) {
+    for (size_t a = 0; a < n_ctx; ++a)
+        for (size_t b = a + 1; b < n_ctx; ++b)
+            if (ctxs[a]->device == ctxs[b]->device) return false;
+    return true;
+}
+
+static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm*>& out, bool owned) {
+    for (size_t t = 0; t < n_ctx; ++t)
+        if (ctxs[t]->comm) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "comm_create_all: context " + std::to_string(t) + " already belongs to a communicator");
+    if (!distinct_devices(ctxs, n_ctx))
+        return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "comm_create_all: RCCL needs one device per rank; two of the contexts are bound to the same device");
+    std::vector<int> devs(n_ctx);
+    for (size_t t = 0; t < n_ctx; ++t) devs[t] = ctxs[t]->device;
+    std::vector<ncclComm_t> nc(n_ctx, nullptr);
+    NCCL_TRY(ctxs[0], ncclCommInitAll(nc.data(), (int)n_ctx, devs.data()));
+    auto clique = std::make_shared<std::vector<p252_comm*>>(n_ctx, nullptr);
+    out.assign(n_ctx, nullptr);
+    int rc = P252_OK;
+    for (size_t t = 0; t < n_ctx; ++t) {
+        p252_comm* c = new p252_comm();
+        c->nccl = nc[t];
+        c->ctx = ctxs[t];
+        c->rank = (int)t;
+        c->world = (int)n_ctx;
+        c->clique = clique;
+        c->owned_by_ctx = owned;
+        (*clique)[t] = c;
+        out[t] = c;
+        ctxs[t]->comm = c;
+        if (rc == P252_OK) rc = alloc_buffers(c);
+    }
+    if (rc == P252_OK) rc = broadcast_and_validate(out, 0);
+    if (rc != P252_OK) {
+        const std::string msg = ctxs[0]->err;
+        for (auto*& c : out) {
+            free_comm(c, true);
+            c = nullptr;
+        }
+        out.clear();
+        ctxs[0]->err = msg;
+    }
+    return rc;
+}
+
+// Sharded tree over the ranks of one single-process clique, everything device-resident and asynchronous: every device
+// reduces its subtree on its stream, ONE grouped ncclAllGather moves the n roots (32 B each) to every device, every device
+// hashes the top levels (<= log4(n) + 1 tiny launches, zero-padded per hash.rs:22-26).  d_root_out[t] (may be NULL)
+// receives the root on device t.
+static int tree_clique(const std::vector<p252_comm*>& comms, const uint64_t tag[4], const void* const* d_leaves, size_t leaves_per_ctx,
+                       void* const* d_root_out, void* const* hip_streams) {
+    const size_t n = comms.size();
+    int rc = P252_OK;
+    for (size_t t = 0; t < n && rc == P252_OK; ++t)
+        rc = merkle_tree_device(comms[t]->ctx, 4, tag, d_leaves[t], leaves_per_ctx, comms[t]->d_sub, nullptr, hip_streams ? hip_streams[t] : nullptr);
+    if (rc == P252_OK) {
+        ncclResult_t r = ncclGroupStart();
+        for (size_t t = 0; t < n && r == ncclSuccess; ++t) {
+            (void)hipSetDevice(comms[t]->ctx->device);
+            r = ncclAllGather(comms[t]->d_sub, comms[t]->d_roots, 32, ncclUint8, comms[t]->nccl, (hipStream_t)(hip_streams ? hip_streams[t] : nullptr));
+        }
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclAllGather of the subtree roots: ") + ncclGetErrorString(r));
+    }
+    for (size_t t = 0; t < n && rc == P252_OK; ++t) {
+        void* dst = (d_root_out && d_root_out[t]) ? d_root_out[t] : comms[t]->d_top;
+        rc = merkle_tree_device(comms[t]->ctx, 4, tag, comms[t]->d_roots, n, dst, nullptr, hip_streams ? hip_streams[t] : nullptr);
+    }
+    if (rc != P252_OK && comms[0]->ctx->err.empty()) comms[0]->ctx->err = "sharded tree failed on another context";
+    return rc;
+}
+
+// used by api.cpp's p252_merkle4_tree_multi_device: RCCL path when the contexts sit on distinct devices (the communicator
+// is created on first use and kept), nullptr-result (-> host gather) when they share a device — RCCL refuses two ranks on
+// one GPU, and that is the single-GPU test configuration — or when P252_MULTI_HOST_GATHER=1 asks for it.
+int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves, size_t leaves_per_ctx,
+                           void* const* d_root_out, void* const* hip_streams, bool* used_rccl) {
+    *used_rccl = false;
+    static const bool host_gather = [] {
+        const char* e = std::getenv("P252_MULTI_HOST_GATHER");
+        return e && e[0] == '1';
+    }();
+    std::vector<p252_comm*> comms = clique_of(ctxs, n_ctx);
+    if (comms.empty()) {
+        if (host_gather || !distinct_devices(ctxs, n_ctx)) return P252_OK;
+        static std::mutex mu;  // one lazy creation at a time
+        std::lock_guard<std::mutex> lk(mu);
+        int rc = create_all(ctxs, n_ctx, comms, /*owned=*/true);
+        if (rc) return rc;
+    }
+    *used_rccl = true;
+    return tree_clique(comms, tag, d_leaves, leaves_per_ctx, d_root_out, hip_streams);
+}
+
+}  // namespace p252host
+
+extern "C" {
+
+int p252_comm_unique_id(void* id_out, size_t len) {
+    if (!id_out || len != P252_COMM_ID_BYTES) return fail(nullptr, P252_ERR_INVALID_ARGUMENT, "comm_unique_id: id_out must hold P252_COMM_ID_BYTES bytes");
+    ncclUniqueId id;
+    NCCL_TRY(nullptr, ncclGetUniqueId(&id));
+    std::memcpy(id_out, id.internal, P252_COMM_ID_BYTES);
+    return P252_OK;
+}
+
+int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, int world, p252_comm** out) {
+    if (!ctx || !out) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: NULL argument");
+    *out = nullptr;
+    if (!id || len != P252_COMM_ID_BYTES) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: id must be the P252_COMM_ID_BYTES bytes of p252_comm_unique_id");
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: need 0 <= rank < world");
+    if (ctx->comm) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: the context already belongs to a communicator");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, P252_COMM_ID_BYTES);
+    ncclComm_t nc = nullptr;
+    NCCL_TRY(ctx, ncclCommInitRank(&nc, world, uid, rank));
+    p252_comm* c = new p252_comm();
+    c->nccl = nc;
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    ctx->comm = c;
+    int rc = alloc_buffers(c);
+    if (rc == P252_OK) rc = broadcast_and_validate(std::vector<p252_comm*>{c}, 0);
+    if (rc != P252_OK) {
+        const std::string msg = ctx->err;
+        free_comm(c, true);
+        ctx->err = msg;
+        return rc;
+    }
+    *out = c;
+    return P252_OK;
+}
+
+int p252_comm_create_all(p252_ctx* const* ctxs, size_t n_ctx, p252_comm** comms_out) {
+    int rc = check_ctxs(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!comms_out) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "comm_create_all: comms_out is NULL");
+    std::vector<p252_comm*> v;
+    rc = create_all(ctxs, n_ctx, v, /*owned=*/false);
+    for (size_t t = 0; t < n_ctx; ++t) comms_out[t] = rc == P252_OK ? v[t] : nullptr;
+    return rc;
+}
+
+void p252_comm_destroy(p252_comm* comm) { free_comm(comm, false); }
+
+int p252_comm_rank(const p252_comm* comm) { return comm ? comm->rank : -1; }
+int p252_comm_size(const p252_comm* comm) { return comm ? comm->world : 0; }
+
+int p252_merkle4_tree_sharded_device(p252_comm* comm, const uint64_t tag[4], const void* d_leaves, size_t n_leaves_local, void* d_root,
+                                     void* hip_stream) {
+    if (!comm || !comm->ctx) return P252_ERR_INVALID_ARGUMENT;
+    p252_ctx* ctx = comm->ctx;
+    if (!tag || !d_leaves || !d_root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree_sharded: NULL buffer");
+    if (!power_of_4(n_leaves_local))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree_sharded: every rank must own a complete subtree (4^k leaves)");
+    // the rank's subtree (zero communication) ...
+    int rc = merkle_tree_device(ctx, 4, tag, d_leaves, n_leaves_local, comm->d_sub, nullptr, hip_stream);
+    if (rc) return rc;
+    // ... the path's only exchange step, on the same stream: world x 32 bytes to every rank ...
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    NCCL_TRY(ctx, ncclAllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, (hipStream_t)hip_stream));
+    // ... and the top levels, on every rank (a single rank's "tree over one root" is a copy)
+    return merkle_tree_device(ctx, 4, tag, comm->d_roots, (size_t)comm->world, d_root, nullptr, hip_stream);
+}
+
+int p252_merkle4_tree_multi_device_resident(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,
+                                            size_t leaves_per_ctx, void* const* d_root_out, void* const* hip_streams) {
+    int rc = check_ctxs(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!tag || !d_leaves) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi_device_resident: NULL buffer");
+    if (!power_of_4(leaves_per_ctx))
+        return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi_device_resident: every device must own a complete subtree (4^k leaves)");
+    bool used = false;
+    rc = tree_multi_device_rccl(ctxs, n_ctx, tag, d_leaves, leaves_per_ctx, d_root_out, hip_streams, &used);
+    if (rc) return rc;
+    if (!used)
+        return fail(ctxs[0], P252_ERR_COMM,
+                    "merkle_tree_multi_device_resident needs an RCCL communicator over the contexts: they share a device (RCCL wants one per rank) "
+                    "or P252_MULTI_HOST_GATHER=1 is set; p252_merkle4_tree_multi_device gathers through the host in that case");
+    return P252_OK;
+}
+
+}  // extern "C"

@@ -46,6 +46,29 @@ def merkle4_tree(leaves, tag=None, ctx=None, want_levels=False):
     return ctx.merkle4_tree(tag, np.asarray(leaves), want_levels=want_levels)
 
 
+def merkle4_forest(leaves, leaves_per_tree, tag=None, ctx=None, want_levels=False):
+    """roots of the n_trees = n / leaves_per_tree independent complete trees stored tree-major in `leaves` (a torch CUDA tensor
+    or an (n,4) uint64 numpy array): one kernel launch per level across all trees.  Returns roots (n_trees,4) — torch int64 on
+    the device for device input, numpy uint64 otherwise — and optionally the level-major array of all levels."""
+    import torch
+    ctx = ctx or Context.default()
+    tag = merkle4_tag() if tag is None else _as_scalars(tag).reshape(4)
+    dev_in = _is_torch(leaves)
+    d = leaves if dev_in else torch.from_numpy(_as_scalars(leaves).reshape(-1, 4).view(np.int64)).to("cuda:%d" % ctx.device)
+    n = d.numel() * d.element_size() // 32
+    if leaves_per_tree < 1 or n % leaves_per_tree:
+        raise ValueError("forest: %d leaves are not a whole number of %d-leaf trees" % (n, leaves_per_tree))
+    n_trees = n // leaves_per_tree
+    roots = torch.empty((n_trees, 4), dtype=torch.int64, device=d.device)
+    levels = torch.empty((max(n_trees * levels_len(leaves_per_tree), 1), 4), dtype=torch.int64, device=d.device) if want_levels else None
+    ctx.merkle4_forest_device(tag, d, n_trees, leaves_per_tree, roots, levels)
+    if not dev_in:
+        torch.cuda.synchronize(d.device)
+        roots = roots.cpu().numpy().view(np.uint64)
+        levels = levels.cpu().numpy().view(np.uint64) if want_levels else None
+    return (roots, levels) if want_levels else roots
+
+
 def merkle4_openings(leaves, levels, indices):
     """Host-side bookkeeping (no hashing): sibling paths of the leaves at `indices` out of a built tree.
     leaves (n,4), levels = concatenated upper levels as merkle4_tree(..., want_levels=True) returns.

@@ -8,6 +8,13 @@
 
 #include "poseidon252_hip.h"
 
+/* the four HIP runtime calls a C caller with device-resident data needs (libamdhip64; declared here so that this file stays
+ * plain C11 without the HIP headers): all return 0 on success; kind 1 = host to device, 2 = device to host */
+extern int hipMalloc(void** ptr, size_t bytes);
+extern int hipFree(void* ptr);
+extern int hipMemcpy(void* dst, const void* src, size_t bytes, int kind);
+extern int hipDeviceSynchronize(void);
+
 #define CHECK(cond)                                                         \
     do {                                                                    \
         if (!(cond)) {                                                      \
@@ -86,6 +93,72 @@ int main(void) {
     uint64_t* out2 = (uint64_t*)malloc(sizeof(uint64_t) * 4 * N);
     CHECK(out2 && p252_hash_batch_multi(ctxs, 3, tag, in, 4, 1, out2, N) == P252_OK && memcmp(out, out2, 32 * N) == 0);
     CHECK(p252_merkle4_tree_multi(ctxs, 3, tag, in, 4 * N, root2) == P252_ERR_INVALID_ARGUMENT); /* 4N/3 is not 4^k */
+    /* device-resident entry points + RCCL inside the library, at one rank on the real backend */
+    {
+        void *d_leaves = NULL, *d_root = NULL, *d_forest = NULL;
+        uint64_t root3[4];
+        CHECK(hipMalloc(&d_leaves, 32 * 4 * (size_t)N) == 0 && hipMalloc(&d_root, 32) == 0 && hipMalloc(&d_forest, 32 * (size_t)N / 4) == 0);
+        CHECK(hipMemcpy(d_leaves, in, 32 * 4 * (size_t)N, 1) == 0);
+        /* one process, an array of contexts on distinct devices: ncclCommInitAll, constants broadcast + validated */
+        p252_comm *comm = NULL, *dup = NULL;
+        CHECK(p252_comm_create_all(&ctx, 1, &comm) == P252_OK && comm != NULL && p252_comm_rank(comm) == 0 && p252_comm_size(comm) == 1);
+        CHECK(p252_comm_create_all(&ctx, 1, &dup) == P252_ERR_INVALID_ARGUMENT && dup == NULL); /* a context belongs to one communicator */
+        /* subtree -> ncclAllGather of the roots on the stream -> top levels: at one rank the tree's own root */
+        CHECK(p252_merkle4_tree_sharded_device(comm, tag, d_leaves, 4 * (size_t)N, d_root, NULL) == P252_OK);
+        CHECK(hipDeviceSynchronize() == 0 && hipMemcpy(root3, d_root, 32, 2) == 0 && memcmp(root3, root, 32) == 0);
+        CHECK(p252_merkle4_tree_sharded_device(comm, tag, d_leaves, 3, d_root, NULL) == P252_ERR_INVALID_ARGUMENT); /* not 4^k */
+        p252_comm_destroy(comm);
+        /* one process per GPU: rank 0 makes the id, every rank joins with it (here: world = 1) */
+        {
+            unsigned char id[P252_COMM_ID_BYTES];
+            p252_comm* cr = NULL;
+            p252_ctx* c2 = NULL;
+            CHECK(p252_create(0, &c2) == P252_OK);
+            CHECK(p252_comm_unique_id(id, sizeof id) == P252_OK && p252_comm_unique_id(id, 5) == P252_ERR_INVALID_ARGUMENT);
+            CHECK(p252_comm_create_rank(c2, id, sizeof id, 0, 1, &cr) == P252_OK && p252_comm_size(cr) == 1);
+            memset(root3, 0, 32);
+            CHECK(p252_merkle4_tree_sharded_device(cr, tag, d_leaves, 4 * (size_t)N, d_root, NULL) == P252_OK);
+            CHECK(hipDeviceSynchronize() == 0 && hipMemcpy(root3, d_root, 32, 2) == 0 && memcmp(root3, root, 32) == 0);
+            CHECK(p252_comm_create_rank(c2, id, sizeof id, 1, 1, &cr) == P252_ERR_INVALID_ARGUMENT); /* rank >= world */
+            p252_destroy(c2); /* context first: the communicator stays a husk to destroy */
+            p252_comm_destroy(cr);
+        }
+        /* the multi-device entry point creates its communicator itself (contexts on distinct devices) and keeps it */
+        {
+            const void* dl[1];
+            void* dr[1];
+            p252_ctx* c3 = NULL;
+            CHECK(p252_create(0, &c3) == P252_OK);
+            dl[0] = d_leaves;
+            dr[0] = d_root;
+            memset(root3, 0, 32);
+            CHECK(p252_merkle4_tree_multi_device(&c3, 1, tag, dl, 4 * (size_t)N, root3) == P252_OK && memcmp(root3, root, 32) == 0);
+            memset(root3, 0, 32);
+            CHECK(p252_merkle4_tree_multi_device_resident(&c3, 1, tag, dl, 4 * (size_t)N, dr, NULL) == P252_OK);
+            CHECK(hipDeviceSynchronize() == 0 && hipMemcpy(root3, d_root, 32, 2) == 0 && memcmp(root3, root, 32) == 0);
+            /* two contexts on ONE device cannot form an RCCL communicator: the resident variant says so ... */
+            {
+                p252_ctx* two[2];
+                const void* dl2[2];
+                two[0] = ctxs[0];
+                two[1] = ctxs[1];
+                dl2[0] = d_leaves;
+                dl2[1] = (const char*)d_leaves + 32 * 2 * (size_t)N;
+                if (p252_device_count() < 2) {
+                    CHECK(p252_merkle4_tree_multi_device_resident(two, 2, tag, dl2, 1024, NULL, NULL) == P252_ERR_COMM);
+                    /* ... and the synchronous one gathers the two roots through the host */
+                    CHECK(p252_merkle4_tree_multi_device(two, 2, tag, dl2, 1024, root3) == P252_OK);
+                }
+            }
+            p252_destroy(c3); /* takes the library-made communicator with it */
+        }
+        /* forest: 1,024 trees of 16 leaves, one launch per level across all trees = level 2 of the big tree above */
+        CHECK(p252_merkle4_forest_device(ctx, tag, d_leaves, (size_t)N / 4, 16, d_forest, NULL, NULL) == P252_OK);
+        CHECK(hipDeviceSynchronize() == 0 && hipMemcpy(out2, d_forest, 32 * (size_t)N / 4, 2) == 0);
+        CHECK(memcmp(out2, levels + 4 * (size_t)N, 32 * (size_t)N / 4) == 0);
+        CHECK(p252_merkle4_forest_device(ctx, tag, d_leaves, 5, 12, d_forest, NULL, NULL) == P252_ERR_INVALID_ARGUMENT);
+        CHECK(hipFree(d_leaves) == 0 && hipFree(d_root) == 0 && hipFree(d_forest) == 0);
+    }
     /* error paths return codes, nothing unwinds */
     CHECK(p252_hash_batch(ctx, tag, in, 0, 1, out, N) == P252_ERR_INVALID_IO_PATTERN && strlen(p252_last_error(ctx)) > 0);
     CHECK(p252_hash_batch(ctx, tag, NULL, 4, 1, out, N) == P252_ERR_INVALID_ARGUMENT);

@@ -47,6 +47,14 @@ static bool throws_io(F f, IoPatternError::Kind kind) {
     return false;
 }
 
+// the HIP runtime calls a caller with device-resident data needs (libamdhip64), declared here: this test builds with plain g++
+extern "C" {
+int hipMalloc(void** ptr, std::size_t bytes);
+int hipFree(void* ptr);
+int hipMemcpy(void* dst, const void* src, std::size_t bytes, int kind);  // 1 = host to device, 2 = device to host
+int hipDeviceSynchronize(void);
+}
+
 int main() {
     // ---- README.md:31-51 ----
     {
@@ -182,6 +190,42 @@ int main() {
             threw = true;
         }
         EXPECT(threw);
+    }
+    // ---- the library's RCCL communicator at one rank (real backend) and the forest entry point, device-resident data ----
+    {
+        const std::size_t n_leaves = 4096, per_tree = 64;  // one 4^6-leaf tree = a forest of 64 trees of 4^3 leaves + one 64-leaf tree on top
+        auto leaves = random_scalars(0xf0e, n_leaves);
+        void *d_leaves = nullptr, *d_root = nullptr, *d_roots = nullptr;
+        EXPECT(hipMalloc(&d_leaves, 32 * n_leaves) == 0 && hipMalloc(&d_root, 32) == 0 && hipMalloc(&d_roots, 32 * n_leaves / per_tree) == 0);
+        EXPECT(hipMemcpy(d_leaves, leaves.data(), 32 * n_leaves, 1) == 0);
+        Context c(0);
+        {
+            Comm comm(c, Comm::unique_id(), 0, 1);
+            EXPECT(comm.rank() == 0 && comm.size() == 1);
+            comm.merkle4_root_sharded_device(d_leaves, n_leaves, d_root);
+            BlsScalar got{};
+            EXPECT(hipDeviceSynchronize() == 0 && hipMemcpy(got.data(), d_root, 32, 2) == 0);
+            EXPECT(got == merkle4_root(leaves));
+        }
+        {
+            Context c1(0);
+            std::vector<Context*> one = {&c1};
+            auto comms = Comm::create_all(one);
+            EXPECT(comms.size() == 1 && comms[0].size() == 1);
+            comms[0].merkle4_root_sharded_device(d_leaves, n_leaves, d_root);
+            BlsScalar got{};
+            EXPECT(hipDeviceSynchronize() == 0 && hipMemcpy(got.data(), d_root, 32, 2) == 0);
+            EXPECT(got == merkle4_root(leaves));
+        }
+        merkle4_forest_device(d_leaves, n_leaves / per_tree, per_tree, d_roots, c);
+        std::vector<BlsScalar> roots(n_leaves / per_tree);
+        EXPECT(hipDeviceSynchronize() == 0 && hipMemcpy(roots.data(), d_roots, 32 * roots.size(), 2) == 0);
+        for (std::size_t t = 0; t < roots.size(); ++t)
+            EXPECT(roots[t] == merkle4_root(std::vector<BlsScalar>(leaves.begin() + t * per_tree, leaves.begin() + (t + 1) * per_tree)));
+        EXPECT(merkle4_root(roots) == merkle4_root(leaves));
+        hipFree(d_leaves);
+        hipFree(d_root);
+        hipFree(d_roots);
     }
     // ---- encrypt / decrypt (src/encryption.rs:62-95; tests/encryption.rs properties), both call sequences ----
     for (int variant : {P252_CRYPT_STREAM, P252_CRYPT_DUPLEX}) {

@@ -13,7 +13,7 @@ def _build(tmp_path):
     exe = str(tmp_path / "abi_smoke")
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L", os.path.join(ROOT, "poseidon252_amd"), "-lposeidon252_hip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "poseidon252_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
+                           "-Wl,-rpath," + os.path.join(ROOT, "poseidon252_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
     return exe
 
 

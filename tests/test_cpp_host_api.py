@@ -13,7 +13,7 @@ def _build(tmp_path):
     cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_hash_api.cpp"),
            "-L", os.path.join(ROOT, "poseidon252_amd"), "-lposeidon252_hip", "-L", os.path.join(ROOT, "oracle"), "-lp252_oracle",
            "-Wl,-rpath," + os.path.join(ROOT, "poseidon252_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
-           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe]
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
     subprocess.check_call(cmd)
     return exe
 

@@ -258,29 +258,48 @@ def test_fold_top_quotient_bounds():
             d.append(v & ((1 << 29) - 1))
             v >>= 29
         return d + [v]
+    def wide_digits(v, push):
+        """the same value in WIDE digits (fr29.hpp redc_w<true>: a column's whole low register read as a signed number,
+        |d| <= 2^31) — what the kernels feed the recurrence for the W terms.  push = +1 / -1 drives every digit to the
+        positive / negative end of its range (the adversarial extreme for a coefficient of that sign), 0 = random transfers."""
+        d = digits(v)
+        for k in range(8):
+            lo, hi = -((2 ** 31 + d[k]) >> 29), (2 ** 31 - 1 - d[k]) >> 29  # transfers that keep d[k] + t 2^29 inside [-2^31, 2^31)
+            t = {1: hi, -1: lo}.get(push, rng.randint(lo, hi))
+            d[k] += t << 29
+            d[k + 1] -= t
+        assert sum(x << (29 * k) for k, x in enumerate(d)) == v and all(-2 ** 31 <= x < 2 ** 31 for x in d[:8])
+        return d
     rng = random.Random(5)
     lim = int(5.3 * P)
-    worst = 0.0
-    for trial in range(20000):
-        cols = [0] * 9
-        for c in coef:
-            if trial % 3 == 0:
-                x = lim if c > 0 else -lim
-            elif trial % 3 == 1:
-                x = -lim if c > 0 else lim
-            else:
-                x = rng.choice([lim, -lim, rng.randrange(-lim, lim)])
-            for k, d in enumerate(digits(x)):
-                cols[k] += d * c
-        for k, d in enumerate(digits(rng.randrange(P))):
-            cols[k] += d
-        V = sum(c << (29 * k) for k, c in enumerate(cols))
-        th = (cols[8] + (cols[7] >> 29)) >> SH
-        assert -2 ** 31 <= th < 2 ** 31
-        q = (th * M) >> 32
-        assert abs(q) < 2 ** 29 and max(abs(c) for c in cols) < 2 ** 62
-        worst = max(worst, abs(V - q * P) / P)
-    assert worst < 1.3, worst
+    n_a = len(pymodel.A_INT)  # the first four terms are U values (carried digits), the other five W values (wide digits)
+    for wide in (False, True):
+        worst, worst_col = 0.0, 0
+        for trial in range(20000):
+            cols = [0] * 9
+            for j, c in enumerate(coef):
+                if trial % 3 == 0:
+                    x, push = (lim if c > 0 else -lim), (1 if c > 0 else -1)
+                elif trial % 3 == 1:
+                    x, push = (-lim if c > 0 else lim), (1 if c > 0 else -1)
+                else:
+                    x, push = rng.choice([lim, -lim, rng.randrange(-lim, lim)]), 0
+                dx = wide_digits(x, push) if (wide and j >= n_a) else digits(x)
+                for k, d in enumerate(dx):
+                    cols[k] += d * c
+            for k, d in enumerate(digits(rng.randrange(P))):
+                cols[k] += d
+            V = sum(c << (29 * k) for k, c in enumerate(cols))
+            th = (cols[8] + (cols[7] >> 29)) >> SH
+            assert -2 ** 31 <= th < 2 ** 31
+            q = (th * M) >> 32
+            worst_col = max(worst_col, max(abs(c) for c in cols))
+            assert abs(q) < 2 ** 29 and worst_col < 2 ** 62
+            worst = max(worst, abs(V - q * P) / P)
+        assert worst < 1.3, (wide, worst)
+        if wide:  # the representation that actually runs (ADVICE r3): wide digits do reach further into the columns
+            assert worst_col > 2 * carried_col, (worst_col, carried_col)
+        carried_col = worst_col
 
 
 def test_digest_path_with_hoisted_tag_sbox(oracle_mod, hosttest_lib):

@@ -66,8 +66,12 @@ def test_one_multiply_add_per_product(isa):
 
 @pytest.mark.gpu
 def test_throughput_floor(gpu_ctx):
-    """floor at 4.0e8 digests/s (the kernel measures 4.5-4.8e8 on every MI355X box seen, driver-timed 4.50e8): a regression
-    of more than ~10 % fails (the old floor of 1.5e8 let a 60 % regression pass)"""
+    """Two floors.  (i) Per clock: the kernel delivers 2.08-2.11e8 digests/s per GHz of shader
+    clock on every MI355X box seen (profiles/r03_bench_boxes.txt); the clock is measured HERE, beside the launches (the
+    bench's one-wave probe), so a shared or thermally throttled box moves the clock, not this ratio — below 1.97e8 per GHz
+    (a regression of ~6 %) fails whatever the box.  (ii) Absolute: 4.4e8 digests/s (4.90-4.95e8 measured on six boxes, driver-timed
+    4.93e8) whenever the chip holds a healthy clock (>= 2.25 GHz under this kernel; 2.33-2.39 seen): a 10 % regression
+    fails.  P252_PERF_STRICT=1 asserts (ii) unconditionally."""
     import torch
     n = 1 << 20
     d_in = torch.randint(0, 2 ** 62, (n * 4, 4), dtype=torch.int64, device="cuda")
@@ -77,12 +81,21 @@ def test_throughput_floor(gpu_ctx):
     for _ in range(40):  # ~90 ms: an idle chip's clocks need ~25 ms of load to reach steady state
         gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = 0.0
+    side = torch.cuda.Stream()
+    best, best_ghz = 0.0, None
     for _ in range(3):
         e0.record()
-        for _ in range(20):
+        gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
+        probe = gpu_ctx.clock_probe(spin_us=20000, stream=side)  # ~20 ms of the 42 ms region, on a second stream
+        for _ in range(19):
             gpu_ctx.hash_batch_device(tag, d_in, 4, 1, d_out, n)
         e1.record()
         torch.cuda.synchronize()
-        best = max(best, 20 * n / (e0.elapsed_time(e1) * 1e-3))
-    assert best > 4.0e8, best
+        rate = 20 * n / (e0.elapsed_time(e1) * 1e-3)
+        ghz = gpu_ctx.clock_probe_result(probe)["shader_ghz"]
+        if rate > best:
+            best, best_ghz = rate, ghz
+    assert 1.0 < best_ghz < 2.7, best_ghz
+    assert best / best_ghz > 1.97e8, (best, best_ghz)
+    if best_ghz >= 2.25 or os.environ.get("P252_PERF_STRICT") == "1":
+        assert best > 4.4e8, (best, best_ghz)

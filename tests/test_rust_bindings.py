@@ -74,3 +74,36 @@ def test_run_parity_script_names_only_files_that_exist():
     assert out["ok"] and out["tests"] == {"gpu_matches_reference_hash": "ok"} and out["encryption"]["21"]["stream"] is True
     assert out["tag_inputs"]["merkle4_4_1"]["bytes"] == [128, 0, 0, 4]
     assert "p252_abi_version()" in open(os.path.join(rust, "src", "lib.rs")).read()
+
+
+def test_rustparity_expected_is_the_librarys_prediction():
+    """bindings/rust/RUSTPARITY.expected.json holds what the library predicts the parity run will print —
+    kept in sync with the library's host helpers (and an independent hashlib re-derivation) by the generator; run_parity.sh
+    diffs its result against it.  Here: in sync, every pattern parity.rs prints is predicted, and the differ works."""
+    import json
+    gen = os.path.join(ROOT, "tools", "gen_rustparity_expected.py")
+    r = subprocess.run([sys.executable, gen, "--check"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    exp = json.load(open(os.path.join(ROOT, "bindings", "rust", "RUSTPARITY.expected.json")))
+    parity = open(os.path.join(ROOT, "bindings", "rust", "tests", "parity.rs")).read()
+    printed = set(re.findall(r'\\"pattern\\": \\"([a-z0-9_+]+)\\"', parity)) | set(re.findall(r'\("([a-z0-9_+]+)", Domain::', parity))
+    assert printed == set(exp["tag_inputs"]) and set(exp["encryption"]) == {"2", "21", "42"}, (printed, set(exp["tag_inputs"]))
+    assert exp["tag_inputs"]["merkle4_4_1"]["bytes"] == [0x80, 0, 0, 4, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0xF]
+    assert exp["tag_inputs"]["other_42_1"] == dict(exp["tag_inputs"]["other_3+39_1"], pattern="other_42_1")  # adjacent absorbs aggregate
+    assert [exp["encryption"][k]["duplex"] for k in ("2", "21", "42")] == [True, False, False]
+    assert "RUSTPARITY.expected.json" in open(os.path.join(ROOT, "bindings", "rust", "run_parity.sh")).read() or "--diff RUSTPARITY.json" in open(os.path.join(ROOT, "bindings", "rust", "run_parity.sh")).read()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        same = os.path.join(d, "same.json")
+        json.dump(dict(exp, log="RUSTPARITY.log"), open(same, "w"))
+        r = subprocess.run([sys.executable, gen, "--diff", same], capture_output=True)
+        assert r.returncode == 0 and b"PINNED" in r.stdout
+        other = json.loads(json.dumps(exp))
+        other["tag_inputs"]["merkle4_4_1"]["bytes"][0] = 0
+        other["encryption"]["21"]["stream"], other["encryption"]["21"]["duplex"] = False, True
+        del other["tag_inputs"]["other_42_5"]
+        json.dump(other, open(same, "w"))
+        r = subprocess.run([sys.executable, gen, "--diff", same], capture_output=True)
+        lines = r.stdout.decode().splitlines()
+        assert r.returncode == 1 and len(lines) == 4, lines
+        assert any("tag_inputs.merkle4_4_1.bytes" in l for l in lines) and any("encryption.21.stream" in l for l in lines) and any("missing from the run" in l for l in lines)
