@@ -721,6 +721,7 @@ def main():
         sys.exit(2)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver); before the runtime loads
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

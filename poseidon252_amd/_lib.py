@@ -74,11 +74,14 @@ def _preload_torch_hip_runtime():
         ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     except OSError:
         return None
-    # the same for RCCL (the library links librccl.so.1 since ABI 6; torch bundles a copy under that SONAME): one copy per process
+    # the same for RCCL (the library links librccl.so.1 since ABI 6; torch bundles a copy under that SONAME): one copy per
+    # process.  NOT with RTLD_GLOBAL: a globally visible librccl ahead of `import torch` makes the process abort at exit
+    # ("double free or corruption": tests/test_gpu_parity.py::test_library_loaded_before_torch_leaves_torch_usable);
+    # a local load is enough — the loader satisfies the library's NEEDED entry from any loaded object of that SONAME
     rccl = os.path.join(os.path.dirname(path), "librccl.so")
     if os.path.exists(rccl):
         try:
-            ctypes.CDLL(rccl, mode=ctypes.RTLD_GLOBAL)
+            ctypes.CDLL(rccl)
         except OSError:
             pass
     return path

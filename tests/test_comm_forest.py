@@ -172,3 +172,17 @@ def test_forest_argument_errors(gpu_ctx):
     with pytest.raises(ValueError):
         P.merkle4_forest(d, 5)  # 48 leaves are not whole 5-leaf trees
     gpu_ctx.merkle4_forest_device(P.merkle4_tag(), d, 0, 16, r)  # an empty forest is a no-op
+
+
+def test_library_before_torch_exits_cleanly():
+    """Found on the GPU box in round 4: with torch's bundled librccl pre-loaded RTLD_GLOBAL ahead of `import torch` the
+    process aborted at exit ("double free or corruption").  _lib.py loads it locally now (one RCCL per process all the
+    same: the loader satisfies the library's NEEDED librccl.so.1 from any loaded object of that SONAME).  Reproducible
+    without a GPU: load the library first, import torch, exit."""
+    import sys
+    code = ("from poseidon252_amd import _lib\n_lib.lib()\nimport torch\n"
+            "print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l)))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()[-2000:]
+    libs = eval(r.stdout.decode().strip().splitlines()[-1])
+    assert len(libs) == 1, libs  # torch's copy serves both
