@@ -18,6 +18,8 @@ runs this one command:
   secondary.tree      BASELINE configs[2]: 2^24-leaf arity-4 Merkle tree per GPU, all levels; at N > 1 every rank
                       reduces its subtree, the N roots (32 B each) are all-gathered — the path's only exchange step —
                       and the top levels are hashed on every rank: at N = 8 that IS configs[4] (2^27 leaves)
+  secondary.forest    the same 2^24 leaves per GPU as 4,096 independent trees of 4^6 leaves (p252_merkle4_forest_device: one launch per
+                      level across all trees — the downstream poseidon-merkle shape; no narrow levels left to wait for)
   secondary.sponge42  BASELINE configs[3]: Domain::Other sponge, 2^20 messages x 42 scalars -> 5 outputs per GPU
   secondary.openings  SURVEY §8 f3: 2^20 Merkle4 openings of depth 12 per GPU (branch re-hash, k_merkle4_path_lines)
   secondary.encrypt   SURVEY §8 f4: 2^20 encryptions of 2-scalar messages per GPU (k_crypt; construction unpinned)
@@ -48,10 +50,10 @@ sys.path.insert(0, ROOT)
 
 # algorithmic figures
 MACS_PER_PERM_REFERENCE = 256_000      # 2000 field mults x 128 32x32->64 MACs (reference schedule)
-BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "sponge42": 1504.0 / 12.0,
+BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "forest": (4096 * 32 + 32) / 1365.0, "sponge42": 1504.0 / 12.0,
                   "openings": (32 + 12 * 96 + 12 + 32) / 12.0,  # leaf + 12 x 3 siblings + 12 position bytes + root
                   "encrypt": (5 * 32 + 3 * 32) / 2.0}             # 2 message + 2 secret + 1 nonce scalars in, 3 cipher scalars out
-KERNEL_OF = {"merkle4_digests": "k_merkle4", "tree": "k_merkle4", "sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}
+KERNEL_OF = {"merkle4_digests": "k_merkle4", "tree": "k_merkle4", "forest": "k_merkle4", "sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}
 # VALU issue peak of the chip (the binding roofline): a wave64 v_mad_i64_i32 occupies its SIMD for 4
 # cycles, so 1024 SIMDs x clock / 4 wave-instructions/s; x 64 lanes = lane-MACs/s.  At the nominal 2.4 GHz that is
 # 614.4 G wave-instructions/s = 39.3 T lane-MACs/s — `peak`.  The clock the chip actually holds under this load is lower
@@ -101,7 +103,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # the clocks need ~10 launches (25 ms) to ramp from idle
-    ap.add_argument("--workload", default=None, choices=["merkle4_digests", "tree", "sponge42", "openings", "encrypt"],
+    ap.add_argument("--workload", default=None, choices=["merkle4_digests", "tree", "forest", "sponge42", "openings", "encrypt"],
                     help="primary workload (default merkle4_digests = BASELINE configs[1], followed by the secondary workloads)")
     ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step of the primary (default: 20; tree: 24 leaves)")
     ap.add_argument("--no-secondary", action="store_true", help="do not time the secondary workloads (tree, sponge42)")
@@ -131,7 +133,8 @@ def pmc_profile(kernel):
 
 def pmc_traffic(kernel, workload, units_per_launch):
     """HBM bytes per step from the committed --pmc passes of the kernel(s) the workload runs, scaled to this size"""
-    d = pmc_profile(kernel if workload != "tree" else "tree")
+    # (a forest is built level by level like a tree: per permutation it moves what the tree's passes show)
+    d = pmc_profile(kernel if workload not in ("tree", "forest") else "tree")
     if not d or "hbm_bytes_per_launch" not in d:
         return None
     if d["stale"]:
@@ -139,7 +142,7 @@ def pmc_traffic(kernel, workload, units_per_launch):
     scale = units_per_launch / d["units_per_launch"]
     out = {"bytes": d["hbm_bytes_per_launch"] * scale, "algorithmic_bytes": BYTES_PER_PERM[workload] * units_per_launch,
            "ratio": d["hbm_bytes_per_launch"] * scale / (BYTES_PER_PERM[workload] * units_per_launch), "source": d["source"]}
-    if workload == "tree":
+    if workload in ("tree", "forest"):
         # SURVEY §8d's figure counts the leaves in and the root out; a level-by-level build also writes every level and reads it
         # back (nodes x 64 B): that is what the counters must be compared with to see wasted re-reads
         lbl = BYTES_PER_PERM[workload] * units_per_launch + 64.0 * (units_per_launch - 1)
@@ -280,6 +283,8 @@ def cpu_baseline(tag, gpu_samples=()):
     for name, kind, stag, inp, in_len, out_len, got in gpu_samples:
         if kind == "tree":
             exp = oracle.merkle4_tree(stag, inp)[0]
+        elif kind == "forest":  # inp = (trees, leaves_per_tree, 4): one oracle tree each
+            exp = np.stack([oracle.merkle4_tree(stag, t)[0] for t in inp])
         elif kind == "encrypt":
             exp = oracle.encrypt_batch(stag, np.ascontiguousarray(inp[0]), np.ascontiguousarray(inp[1]), np.ascontiguousarray(inp[2]))
         elif kind == "paths":
@@ -404,6 +409,17 @@ def make_workload(E, wl, log2n):
         in_scalars, W.perms_per_step = n, P.levels_len(n)
         W.name = "2^%d-leaf arity-4 Merkle tree per GPU, all levels (BASELINE configs[2])" % log2n
         W.wake = 6
+    elif wl == "forest":
+        log2n = log2n or 24
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        W.per_tree = 4 ** 6 if n >= 4 ** 8 else 4 ** 2
+        W.n_trees = n // W.per_tree
+        in_scalars, W.perms_per_step = n, W.n_trees * P.levels_len(W.per_tree)
+        BYTES_PER_PERM["forest"] = (W.per_tree * 32 + 32) / float(P.levels_len(W.per_tree))  # leaves in, root out, per tree
+        W.name = ("forest of %d independent arity-4 Merkle trees of 4^%d leaves per GPU (2^%d leaves; p252_merkle4_forest_device: one launch per level "
+                  "across all trees; the poseidon-merkle shape, AGENTS.md:62-66)" % (W.n_trees, 6 if W.per_tree == 4 ** 6 else 2, log2n))
+        W.wake = 6
     elif wl == "encrypt":
         log2n = log2n or 20
         n = 1 << log2n
@@ -481,6 +497,10 @@ def make_workload(E, wl, log2n):
                            " = the BASELINE configs[4] composition (8 subtrees, roots gathered, top [n0, n1, 0, 0]) scaled down to 8 x 2^%d leaves" % log2n)
             W.root_hex = lambda: "".join("%016x" % (int(v) & 0xFFFFFFFFFFFFFFFF) for v in reversed(W.d_top.cpu().tolist()))
         W.step()  # allocate the context-owned level scratch outside the timed region
+    elif wl == "forest":
+        d_out = torch.empty((W.n_trees, 4), dtype=torch.int64, device=dev)
+        W.step = lambda: ctx.merkle4_forest_device(tag, d_in, W.n_trees, W.per_tree, d_out)
+        W.step()  # (context-owned level scratch, outside the timed region)
     elif wl == "encrypt":
         d_out = torch.empty((n, 3, 4), dtype=torch.int64, device=dev)
         d_msgs, d_secrets, d_nonces = d_in[:2 * n], d_in[2 * n:4 * n], d_in[4 * n:]
@@ -523,6 +543,11 @@ def make_workload(E, wl, log2n):
             again = P.merkle4_tree(gathered.to(dev).view(world, 4).contiguous(), tag=tag, ctx=ctx)
             torch.cuda.synchronize()
             return bool(torch.equal(top, ref) and torch.equal(again, W.d_top))
+        if wl == "forest":  # a few trees built on their own by the single-tree entry point
+            pick = sorted(set([0, W.n_trees // 3, W.n_trees - 1]))
+            alone = torch.stack([P.merkle4_tree(d_in[t * W.per_tree:(t + 1) * W.per_tree], tag=tag, ctx=ctx) for t in pick])
+            torch.cuda.synchronize()
+            return bool(torch.equal(alone, d_out[pick]))
         if wl == "encrypt":
             # decrypting what was just produced gives the messages back, with every authentication flag set
             back = torch.empty((n, 2, 4), dtype=torch.int64, device=dev)
@@ -551,6 +576,10 @@ def make_workload(E, wl, log2n):
             sub = min(n, 1 << 12)
             got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
             return ("tree", tag, d_in[:sub].cpu().numpy().view(np.uint64), None, None, got)
+        if wl == "forest":  # four trees of what was just timed, leaves and roots
+            pick = sorted(set([0, W.n_trees // 2, W.n_trees - 2, W.n_trees - 1]))
+            leaves = torch.stack([d_in[t * W.per_tree:(t + 1) * W.per_tree] for t in pick]).cpu().numpy().view(np.uint64)
+            return ("forest", tag, leaves, None, None, d_out[pick].cpu().numpy().view(np.uint64))
         if wl == "merkle4_digests":
             idx = torch.arange(0, n, max(1, n // 512), device=dev)
             return ("hash", tag, d_in.view(n, 4, 4)[idx].cpu().numpy().view(np.uint64), 4, 1, d_out[idx].cpu().numpy().view(np.uint64).reshape(-1, 1, 4))
@@ -765,7 +794,7 @@ def main():
 
     primary_key = args.workload or "merkle4_digests"
     # BASELINE configs[2] / [3] (configs[4] at 8 ranks), then the SURVEY §8(f) rows that have kernels of their own
-    secondary_keys = [] if (args.workload or args.no_secondary) else ["tree", "sponge42", "openings", "encrypt"]
+    secondary_keys = [] if (args.workload or args.no_secondary) else ["tree", "forest", "sponge42", "openings", "encrypt"]
     sclk0 = sysfs_sclk_mhz(torch, local_rank)
 
     def measure(key, log2n, steps, warmup):
@@ -822,7 +851,7 @@ def main():
         s_warm = min(args.warmup, 5)
         s_log2n = None
         if args.secondary_log2n is not None:
-            s_log2n = args.secondary_log2n + (4 if key == "tree" else 0)
+            s_log2n = args.secondary_log2n + (4 if key in ("tree", "forest") else 0)
         W2, el2, lm2, cb2, ca2, ok2, sample2 = measure(key, s_log2n, s_steps, s_warm)
         if sample2:
             samples.append((key,) + sample2)

@@ -48,14 +48,19 @@ print("%d Merkle4 digests in batches of 1 .. 70,000 bit-exact" % checked)
 if "--long" in sys.argv:
     from poseidon252_amd import encryption as E
     minutes = float(sys.argv[sys.argv.index("--long") + 1]) if len(sys.argv) > sys.argv.index("--long") + 1 else 5.0
-    counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0, "tree updates": 0}
+    counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0, "tree updates": 0,
+              "forest trees": 0, "sharded-tree leaves (RCCL, one rank)": 0}
+    from poseidon252_amd import comm as C
+    comm_ctx = P.Context(0)
+    comm1 = C.Comm.create_rank(comm_ctx, 0, 1, lambda b: b)  # the library's RCCL communicator on the real backend (round 4)
+    tag2 = oracle.tag(1, [2], 1)
     P_ = oracle.P
     t0 = time.time()
     it = 0
     while time.time() - t0 < 60 * minutes:
         it += 1
         seed = int(rng.integers(1, 1 << 30))
-        kind = it % 9
+        kind = it % 11
         n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 8193)), int(rng.integers(8193, 20000))]))
         if kind == 0:
             n = min(n, 12000)
@@ -131,6 +136,42 @@ if "--long" in sys.argv:
             o_root, o_levels, _ = oracle.merkle4_tree(mtag, upd, want_levels=True)
             assert np.array_equal(d_levels.cpu().numpy().view(np.uint64)[:total], o_levels) and np.array_equal(d_root.cpu().numpy().view(np.uint64), o_root), ("update", leaves_n, k, seed)
             counts["tree updates"] += k
+        elif kind == 9:  # forests: one launch per level across all trees, both arities, levels layout included
+            import torch
+            arity = int(rng.choice([4, 2]))
+            per = arity ** int(rng.integers(0, 7 if arity == 4 else 11))
+            n_trees = int(min(rng.choice([1, int(rng.integers(1, 50)), int(rng.integers(50, 3000))]), max(1, 400000 // per)))
+            lv = oracle.fill_random(seed, n_trees * per)
+            d = torch.from_numpy(lv.view(np.int64).copy()).cuda()
+            total = oracle.levels_total(per) if arity == 4 else per - 1
+            d_roots = torch.zeros((n_trees, 4), dtype=torch.int64, device="cuda")
+            d_levels = torch.zeros((max(n_trees * total, 1), 4), dtype=torch.int64, device="cuda")
+            ftag = mtag if arity == 4 else tag2
+            ctx.merkle4_forest_device(ftag, d, n_trees, per, d_roots, d_levels, arity=arity)
+            torch.cuda.synchronize()
+            roots, levels = d_roots.cpu().numpy().view(np.uint64), d_levels.cpu().numpy().view(np.uint64)
+            for t in sorted(set(int(v) for v in rng.integers(0, n_trees, size=min(n_trees, 12)))):
+                leaf = lv[t * per:(t + 1) * per]
+                if per == 1:
+                    assert np.array_equal(roots[t], leaf[0]), ("forest", arity, per, n_trees, seed)
+                    continue
+                o_root, o_levels, _ = (oracle.merkle4_tree if arity == 4 else oracle.merkle2_tree)(ftag, leaf, want_levels=True)
+                assert np.array_equal(roots[t], o_root), ("forest root", arity, per, n_trees, t, seed)
+                off_f, off_t, width = 0, 0, per // arity
+                while width >= 1:
+                    assert np.array_equal(levels[off_f + t * width:off_f + (t + 1) * width], o_levels[off_t:off_t + width]), ("forest levels", arity, per, n_trees, t, width, seed)
+                    off_f, off_t, width = off_f + n_trees * width, off_t + width, width // arity
+            counts["forest trees"] += n_trees
+        elif kind == 10:  # subtree -> ncclAllGather of the roots on the stream -> top levels, inside the library
+            import torch
+            leaves_n = 4 ** int(rng.integers(0, 10))
+            lv = oracle.fill_random(seed, leaves_n)
+            d = torch.from_numpy(lv.view(np.int64).copy()).cuda()
+            d_root = torch.zeros(4, dtype=torch.int64, device="cuda")
+            comm1.merkle4_tree_sharded_device(mtag, d, leaves_n, d_root)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_root.cpu().numpy().view(np.uint64), oracle.merkle4_tree(mtag, lv)[0]), ("sharded", leaves_n, seed)
+            counts["sharded-tree leaves (RCCL, one rank)"] += leaves_n
         else:
             import torch
             raw = np.frombuffer(np.random.default_rng(seed).bytes(32 * n), dtype=np.uint8).reshape(n, 32)

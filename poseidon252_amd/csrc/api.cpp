@@ -268,13 +268,14 @@ int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
 // array of n_trees * 4^(k-l) nodes, tree-major — so the forest is the first k levels of the level-by-level reduction of
 // the concatenated leaves, and each level is ONE launch across all trees: the narrow upper levels of many small trees
 // fill the chip together instead of each paying one wave's latency per tree.
-int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
-                               void* d_roots, void* d_levels, void* hip_stream) {
+static int forest_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
+                         void* d_roots, void* d_levels, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (n_trees == 0) return P252_OK;
-    if (!power_of_4(leaves_per_tree)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_forest: leaves_per_tree must be 4^k");
-    if (n_trees > (SIZE_MAX / 32) / leaves_per_tree) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_forest: size overflow");
-    if (!tag || !d_leaves || !d_roots) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_forest: NULL buffer");
+    const bool pow_ok = arity == 4 ? power_of_4(leaves_per_tree) : (leaves_per_tree != 0 && (leaves_per_tree & (leaves_per_tree - 1)) == 0);
+    if (!pow_ok) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_forest: leaves_per_tree must be arity^k");
+    if (n_trees > (SIZE_MAX / 32) / leaves_per_tree) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_forest: size overflow");
+    if (!tag || !d_leaves || !d_roots) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_forest: NULL buffer");
     if (misaligned(d_leaves) || misaligned(d_roots) || misaligned(d_levels)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
@@ -284,21 +285,21 @@ int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void*
         return P252_OK;
     }
     if (!d_levels) {  // ping-pong in context-owned scratch (the last level goes straight to d_roots)
-        int rc = ensure(ctx, &ctx->d_lvl[0], &ctx->d_lvl_cap[0], cur_n / 4 * 32);
+        int rc = ensure(ctx, &ctx->d_lvl[0], &ctx->d_lvl_cap[0], cur_n / arity * 32);
         if (rc) return rc;
-        rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], cur_n / 16 * 32 + 32);
+        rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], cur_n / arity / arity * 32 + 32);
         if (rc) return rc;
     }
     const TagArg t = tag_arg(tag);
     const char* cur = static_cast<const char*>(d_leaves);
     char* lv = static_cast<char*>(d_levels);
     // narrow levels after wide ones are computed redundantly on every SIMD, as in the tree builder (clock dip)
-    const size_t pad = cur_n / 4 > 65536 ? 65536 : 0;
+    const size_t pad = cur_n / arity > 65536 ? 65536 : 0;
     int parity = 0;
     while (cur_n > n_trees) {
-        const size_t next_n = cur_n / 4;
+        const size_t next_n = cur_n / arity;
         char* next = next_n == n_trees ? static_cast<char*>(d_roots) : (d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]));
-        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, 4, pad));
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, arity, pad));
         if (d_levels) {
             if (next_n == n_trees) HIP_TRY(ctx, hipMemcpyAsync(lv, d_roots, next_n * 32, hipMemcpyDeviceToDevice, st));  // levels hold the roots too
             lv += next_n * 32;
@@ -308,6 +309,16 @@ int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void*
         parity ^= 1;
     }
     return P252_OK;
+}
+
+int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
+                               void* d_roots, void* d_levels, void* hip_stream) {
+    return forest_device(ctx, 4, tag, d_leaves, n_trees, leaves_per_tree, d_roots, d_levels, hip_stream);
+}
+
+int p252_merkle2_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
+                               void* d_roots, void* d_levels, void* hip_stream) {
+    return forest_device(ctx, 2, tag, d_leaves, n_trees, leaves_per_tree, d_roots, d_levels, hip_stream);
 }
 
 int p252_merkle2_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,

@@ -222,17 +222,18 @@ class Context:
                                                          d_levels.data_ptr() if d_levels is not None else None,
                                                          self._stream()))
 
-    def merkle4_forest_device(self, tag, d_leaves, n_trees, leaves_per_tree, d_roots, d_levels=None):
+    def merkle4_forest_device(self, tag, d_leaves, n_trees, leaves_per_tree, d_roots, d_levels=None, arity=4):
         """n_trees independent complete 4^k-leaf trees, tree-major in d_leaves: one launch per level across ALL trees
         (p252_merkle4_forest_device); d_roots (n_trees, 4); d_levels: level-major, n_trees * levels_len(leaves_per_tree) scalars"""
         tag = _as_scalars(tag).reshape(4)
         assert d_leaves.is_cuda and d_roots.is_cuda and d_leaves.is_contiguous() and d_roots.is_contiguous()
         assert self._nbytes(d_leaves) >= n_trees * leaves_per_tree * 32 and self._nbytes(d_roots) >= n_trees * 32
         if d_levels is not None:
-            assert self._nbytes(d_levels) >= n_trees * _lib.lib().p252_merkle4_levels_len(leaves_per_tree) * 32
-        self._check(_lib.lib().p252_merkle4_forest_device(self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), n_trees, leaves_per_tree,
-                                                           d_roots.data_ptr(), d_levels.data_ptr() if d_levels is not None else None,
-                                                           self._stream()))
+            ll = _lib.lib().p252_merkle4_levels_len if arity == 4 else _lib.lib().p252_merkle2_levels_len
+            assert self._nbytes(d_levels) >= n_trees * ll(leaves_per_tree) * 32
+        fn = _lib.lib().p252_merkle4_forest_device if arity == 4 else _lib.lib().p252_merkle2_forest_device
+        self._check(fn(self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), n_trees, leaves_per_tree,
+                       d_roots.data_ptr(), d_levels.data_ptr() if d_levels is not None else None, self._stream()))
 
     # ---- SURVEY §8(f) rows: truncated outputs on the device, batched Merkle openings ----
     def truncate250_device(self, d_scalars, d_out, n):

@@ -186,3 +186,31 @@ def test_library_before_torch_exits_cleanly():
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()[-2000:]
     libs = eval(r.stdout.decode().strip().splitlines()[-1])
     assert len(libs) == 1, libs  # torch's copy serves both
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_trees,per", [(512, 2 ** 7), (3, 2), (70000, 4), (5, 2 ** 12)])
+def test_merkle2_forest_equals_per_tree_oracle_roots(gpu_ctx, oracle_mod, n_trees, per):
+    """arity 2 (Domain::Merkle2 nodes): the same entry point shape, p252_merkle2_forest_device"""
+    import torch
+    import poseidon252_amd as P
+    tag = P.compute_tag(P.Domain.Merkle2, [2], 1)
+    lv = oracle_mod.fill_random(0xF2 + n_trees + per, n_trees * per)
+    d = torch.from_numpy(lv.view(np.int64)).to("cuda:0")
+    roots = torch.empty((n_trees, 4), dtype=torch.int64, device="cuda:0")
+    n_lv = n_trees * (per - 1)  # a complete binary tree over `per` leaves has per - 1 inner nodes
+    levels = torch.empty((n_lv, 4), dtype=torch.int64, device="cuda:0")
+    gpu_ctx.merkle4_forest_device(tag, d, n_trees, per, roots, levels, arity=2)
+    torch.cuda.synchronize()
+    roots, levels = roots.cpu().numpy().view(np.uint64), levels.cpu().numpy().view(np.uint64)
+    for t in sorted(set([0, n_trees - 1] + list(range(0, n_trees, max(1, n_trees // 25))))):
+        r, lvls, _ = oracle_mod.merkle2_tree(tag, lv[t * per:(t + 1) * per], want_levels=True)
+        assert np.array_equal(roots[t], r), t
+        off_forest, off_tree, width = 0, 0, per // 2
+        while width >= 1:
+            assert np.array_equal(levels[off_forest + t * width: off_forest + (t + 1) * width], lvls[off_tree:off_tree + width]), (t, width)
+            off_forest += n_trees * width
+            off_tree += width
+            width //= 2
+    with pytest.raises(ValueError):
+        gpu_ctx.merkle4_forest_device(tag, d, 1, 12, roots, None, arity=2)  # 12 is not 2^k
