@@ -108,6 +108,7 @@ def parse():
     ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step of the primary (default: 20; tree: 24 leaves)")
     ap.add_argument("--no-secondary", action="store_true", help="do not time the secondary workloads (tree, sponge42)")
     ap.add_argument("--secondary-log2n", type=int, default=None, help="(tests) scale the secondary workloads: 2^k sponge messages, 2^(k+4) tree leaves")
+    ap.add_argument("--secondary-timeout", type=int, default=240, help="N > 1: seconds a secondary workload may take before the line is printed without it (0 = no watchdog)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -846,7 +847,31 @@ def main():
 
     # ---- secondary workloads: the other BASELINE configs, same discipline, same command ----
     secondary = {}
+    # Watchdog (N > 1 only): the primary line above is what the scaling curve is made of.  A secondary workload that HANGS — a
+    # collective that never completes on a node this code has never seen (no 8-GPU box was ever available to the builder) — must
+    # cost that workload, not the run: past the deadline rank 0 prints the line with what is measured so far plus
+    # `secondary_timeout`, and every rank leaves.  The deadline is per workload and generous (the largest takes < 10 s at full size).
+    import threading
+    watch = {"deadline": None, "key": None}
+
+    def watchdog():
+        while True:
+            time.sleep(1.0)
+            dl = watch["deadline"]
+            if dl is not None and time.time() > dl:
+                if rank == 0 and line is not None:
+                    line["secondary"] = secondary
+                    line["secondary_timeout"] = {"workload": watch["key"], "seconds": args.secondary_timeout,
+                                                 "note": "this secondary workload did not finish; the primary figures above are complete"}
+                    print(json.dumps(line), flush=True)
+                print("bench.py rank %d: secondary workload %r exceeded %d s — leaving" % (rank, watch["key"], args.secondary_timeout), file=sys.stderr, flush=True)
+                os._exit(0)
+    if world > 1 and secondary_keys and args.secondary_timeout > 0:
+        threading.Thread(target=watchdog, daemon=True).start()
     for key in secondary_keys:
+        watch["key"], watch["deadline"] = key, time.time() + args.secondary_timeout
+        if os.environ.get("P252_BENCH_TEST_HANG") == key:  # test-only: a workload that never returns (tests the watchdog)
+            time.sleep(10 ** 6)
         s_steps = max(2, min(args.steps, 20))
         s_warm = min(args.warmup, 5)
         s_log2n = None
@@ -875,6 +900,7 @@ def main():
             }
         del W2
         torch.cuda.empty_cache()
+    watch["deadline"] = None
 
     if rank == 0:
         if secondary_keys:

@@ -49,3 +49,22 @@ for n_trees, per in ((1024, 4 ** 6), (4096, 4 ** 6), (4096, 4 ** 4), (65536, 4 *
         ok = all(np.array_equal(r[t], oracle.merkle4_tree(tag, h[t * per:(t + 1) * per])[0]) for t in range(0, n_trees, max(1, n_trees // 16)))
         line += "   oracle sample: %s" % ("ok" if ok else "MISMATCH")
     print(line, flush=True)
+
+# host leaves -> host roots (pageable numpy memory): p252_merkle4_forest streams whole trees through the staging lanes
+import time
+for n_trees, per in ((4096, 4 ** 6), (65536, 4 ** 3)):
+    h = synth.splitmix_scalars(0xF1, n_trees * per, dev).cpu().numpy().view(np.uint64)
+    ctx.merkle4_forest(tag, h, per)
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter()
+        r = ctx.merkle4_forest(tag, h, per)
+        best = min(best, time.perf_counter() - t0)
+    perms = n_trees * P.levels_len(per)
+    line = "host forest %6d trees x 4^%d leaves (%d MiB pageable): %8.3f ms  %.3e perm/s  %.1f GB/s of leaves" % (
+        n_trees, round(np.log2(per) / 2), n_trees * per * 32 >> 20, best * 1e3, perms / best, n_trees * per * 32 / best / 1e9)
+    if "--check" in sys.argv:
+        import oracle
+        ok = all(np.array_equal(r[t], oracle.merkle4_tree(tag, h[t * per:(t + 1) * per])[0]) for t in range(0, n_trees, max(1, n_trees // 16)))
+        line += "   oracle sample: %s" % ("ok" if ok else "MISMATCH")
+    print(line, flush=True)

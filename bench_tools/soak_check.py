@@ -150,6 +150,8 @@ if "--long" in sys.argv:
             ctx.merkle4_forest_device(ftag, d, n_trees, per, d_roots, d_levels, arity=arity)
             torch.cuda.synchronize()
             roots, levels = d_roots.cpu().numpy().view(np.uint64), d_levels.cpu().numpy().view(np.uint64)
+            if arity == 4:  # the host-buffer twin (staged through the lanes when the forest is several chunks)
+                assert np.array_equal(ctx.merkle4_forest(ftag, lv, per), roots), ("host forest", per, n_trees, seed)
             for t in sorted(set(int(v) for v in rng.integers(0, n_trees, size=min(n_trees, 12)))):
                 leaf = lv[t * per:(t + 1) * per]
                 if per == 1:

@@ -304,6 +304,19 @@ class Comm {
     std::shared_ptr<p252_comm> comm_;
 };
 
+// Roots of the leaves.size() / leaves_per_tree independent complete trees stored tree-major in HOST memory
+// (p252_merkle4_forest: whole trees stream through the staging lanes, one forest build per chunk)
+inline std::vector<BlsScalar> merkle4_forest(const std::vector<BlsScalar>& leaves, std::size_t leaves_per_tree,
+                                             Context& ctx = Context::default_context()) {
+    if (leaves_per_tree == 0 || leaves.size() % leaves_per_tree) throw std::invalid_argument("merkle4_forest: not whole trees");
+    const BlsScalar tag = compute_tag(Domain::Merkle4, {4}, 1);
+    std::vector<BlsScalar> roots(leaves.size() / leaves_per_tree);
+    if (!roots.empty())
+        detail::check(p252_merkle4_forest(ctx.get(), tag.data(), leaves[0].data(), roots.size(), leaves_per_tree, roots[0].data()), ctx.get(),
+                      "merkle4_forest");
+    return roots;
+}
+
 // A forest of roots.size() independent complete trees of leaves_per_tree = 4^k device-resident leaves each (tree-major):
 // one launch per level across all trees (p252_merkle4_forest_device); d_roots receives n_trees scalars.
 inline void merkle4_forest_device(const void* d_leaves, std::size_t n_trees, std::size_t leaves_per_tree, void* d_roots,

@@ -56,7 +56,7 @@ extern "C" {
  *   5  + p252_abi_version, p252_merkle4_update_checked_device, p252_clock_probe_device, p252_staging_lanes; out-of-range
  *      indices of p252_merkle4_update_device are skipped (were undefined behaviour)
  *   6  + the RCCL communicator (p252_comm_*), p252_merkle4_tree_sharded_device, p252_merkle4_tree_multi_device_resident,
- *      p252_merkle4_forest_device, p252_merkle2_forest_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
+ *      p252_merkle4_forest[_device], p252_merkle2_forest_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
  *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on) */
 #define P252_ABI_VERSION 6
 
@@ -220,6 +220,11 @@ int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
  * tree t's nodes of that level at t * 4^(k-l) within it.  Asynchronous on hip_stream. */
 int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
                                void* d_roots, void* d_levels, void* hip_stream);
+/* the same from HOST leaves (pageable memory is fine), roots to host memory: whole trees stream through the context's staging lanes
+ * chunk by chunk (32 MiB of leaves each; a forest build per chunk, its inner levels in device-only scratch), so the PCIe copy of
+ * one chunk overlaps the hashing of another; synchronous */
+int p252_merkle4_forest(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_trees, size_t leaves_per_tree,
+                        uint64_t* roots);
 /* the same for arity 2 (Domain::Merkle2 nodes; pass the Merkle2 tag): leaves_per_tree = 2^k, p252_merkle2_levels_len per tree */
 int p252_merkle2_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
                                void* d_roots, void* d_levels, void* hip_stream);

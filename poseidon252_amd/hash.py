@@ -222,6 +222,19 @@ class Context:
                                                          d_levels.data_ptr() if d_levels is not None else None,
                                                          self._stream()))
 
+    def merkle4_forest(self, tag, leaves, leaves_per_tree):
+        """host leaves (numpy, pageable is fine) -> roots (n_trees, 4) numpy: p252_merkle4_forest streams whole trees through the
+        staging lanes, one forest build per chunk"""
+        tag = _as_scalars(tag).reshape(4)
+        lv = _as_scalars(leaves).reshape(-1, 4)
+        if leaves_per_tree < 1 or lv.shape[0] % leaves_per_tree:
+            raise ValueError("forest: %d leaves are not a whole number of %d-leaf trees" % (lv.shape[0], leaves_per_tree))
+        n_trees = lv.shape[0] // leaves_per_tree
+        roots = np.empty((n_trees, 4), dtype=np.uint64)
+        self._check(_lib.lib().p252_merkle4_forest(self._h, tag.ctypes.data_as(_u64p), lv.ctypes.data_as(_u64p), n_trees, leaves_per_tree,
+                                                    roots.ctypes.data_as(_u64p)))
+        return roots
+
     def merkle4_forest_device(self, tag, d_leaves, n_trees, leaves_per_tree, d_roots, d_levels=None, arity=4):
         """n_trees independent complete 4^k-leaf trees, tree-major in d_leaves: one launch per level across ALL trees
         (p252_merkle4_forest_device); d_roots (n_trees, 4); d_levels: level-major, n_trees * levels_len(leaves_per_tree) scalars"""

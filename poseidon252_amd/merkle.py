@@ -50,10 +50,12 @@ def merkle4_forest(leaves, leaves_per_tree, tag=None, ctx=None, want_levels=Fals
     """roots of the n_trees = n / leaves_per_tree independent complete trees stored tree-major in `leaves` (a torch CUDA tensor
     or an (n,4) uint64 numpy array): one kernel launch per level across all trees.  Returns roots (n_trees,4) — torch int64 on
     the device for device input, numpy uint64 otherwise — and optionally the level-major array of all levels."""
-    import torch
     ctx = ctx or Context.default()
     tag = merkle4_tag() if tag is None else _as_scalars(tag).reshape(4)
     dev_in = _is_torch(leaves)
+    if not dev_in and not want_levels:  # host leaves, roots only: the library's staged pipeline (no torch needed)
+        return ctx.merkle4_forest(tag, leaves, leaves_per_tree)
+    import torch
     d = leaves if dev_in else torch.from_numpy(_as_scalars(leaves).reshape(-1, 4).view(np.int64)).to("cuda:%d" % ctx.device)
     n = d.numel() * d.element_size() // 32
     if leaves_per_tree < 1 or n % leaves_per_tree:

@@ -157,6 +157,8 @@ int main(void) {
         CHECK(hipDeviceSynchronize() == 0 && hipMemcpy(out2, d_forest, 32 * (size_t)N / 4, 2) == 0);
         CHECK(memcmp(out2, levels + 4 * (size_t)N, 32 * (size_t)N / 4) == 0);
         CHECK(p252_merkle4_forest_device(ctx, tag, d_leaves, 5, 12, d_forest, NULL, NULL) == P252_ERR_INVALID_ARGUMENT);
+        memset(out2, 0, 32 * (size_t)N / 4); /* the host-buffer twin: leaves in, roots out */
+        CHECK(p252_merkle4_forest(ctx, tag, in, (size_t)N / 4, 16, out2) == P252_OK && memcmp(out2, levels + 4 * (size_t)N, 32 * (size_t)N / 4) == 0);
         CHECK(hipFree(d_leaves) == 0 && hipFree(d_root) == 0 && hipFree(d_forest) == 0);
     }
     /* error paths return codes, nothing unwinds */

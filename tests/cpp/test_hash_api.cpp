@@ -223,6 +223,7 @@ int main() {
         for (std::size_t t = 0; t < roots.size(); ++t)
             EXPECT(roots[t] == merkle4_root(std::vector<BlsScalar>(leaves.begin() + t * per_tree, leaves.begin() + (t + 1) * per_tree)));
         EXPECT(merkle4_root(roots) == merkle4_root(leaves));
+        EXPECT(merkle4_forest(leaves, per_tree, c) == roots);  // the host-buffer twin
         hipFree(d_leaves);
         hipFree(d_root);
         hipFree(d_roots);

@@ -239,6 +239,22 @@ def test_bench_eight_ranks_rehearsal_of_the_driver_command(gpu_ctx, oracle_mod):
         assert w["self_consistency_ok"] is True and w["ranks"] == 8
 
 
+def test_bench_watchdog_prints_the_line_when_a_secondary_hangs(gpu_ctx):
+    """N > 1: a secondary workload that never returns (a collective hanging on a node this code has never seen) must cost that
+    workload, not the run — the primary figures are what the scaling curve is made of.  Past --secondary-timeout rank 0 prints
+    the line with what was measured and `secondary_timeout`, every rank exits 0."""
+    env = dict(os.environ, P252_BENCH_SHARE_GPU="1", P252_BENCH_BACKEND="gloo", P252_BENCH_TEST_HANG="sponge42")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--log2n", "12", "--secondary-log2n", "8", "--secondary-timeout", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, timeout=600, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 1e5 and d["self_consistency_ok"] is True
+    assert d["secondary_timeout"]["workload"] == "sponge42" and sorted(d["secondary"]) == ["forest", "tree"]
+    assert d["secondary"]["tree"]["self_consistency_ok"] is True
+
+
 def test_bench_gpus_flag_launches_the_ranks_itself(gpu_ctx):
     """`python bench.py --gpus 2` with NO launcher: bench.py re-executes itself under torch.distributed.run, so
     --gpus can never be silently ignored.  2 ranks share the one GPU here (test-only switches)."""

@@ -129,7 +129,7 @@ def test_multi_device_entry_point_makes_its_own_communicator(gpu_ctx, oracle_mod
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_trees,per", [(1024, 4 ** 6), (1, 4 ** 5), (3, 4), (7, 16), (4096, 4 ** 3), (70000, 4), (5, 1), (2, 4 ** 9)])
+@pytest.mark.parametrize("n_trees,per", [(1024, 4 ** 6), (1, 4 ** 5), (3, 4), (7, 16), (4096, 4 ** 3), (70000, 4), (5, 1), (2, 4 ** 9), (3001, 4 ** 5)])
 def test_forest_roots_equal_per_tree_oracle_roots(gpu_ctx, oracle_mod, n_trees, per):
     import torch
     import poseidon252_amd as P
@@ -140,7 +140,9 @@ def test_forest_roots_equal_per_tree_oracle_roots(gpu_ctx, oracle_mod, n_trees, 
     torch.cuda.synchronize()
     roots = roots.cpu().numpy().view(np.uint64)
     levels = levels.cpu().numpy().view(np.uint64)
-    roots2 = P.merkle4_forest(lv, per, tag=tag, ctx=gpu_ctx)  # host input, no levels
+    # host leaves, roots only: p252_merkle4_forest — whole trees through the staging lanes, a forest build per chunk (1,024 x 4^6 and
+    # 3,001 x 4^5 leaves are several chunks, the last one ragged; the small shapes take the one-upload path)
+    roots2 = P.merkle4_forest(lv, per, tag=tag, ctx=gpu_ctx)
     assert np.array_equal(roots, roots2)
     idx = sorted(set([0, n_trees - 1] + list(range(0, n_trees, max(1, n_trees // 40)))))
     for t in idx:
@@ -213,4 +215,4 @@ def test_merkle2_forest_equals_per_tree_oracle_roots(gpu_ctx, oracle_mod, n_tree
             off_tree += width
             width //= 2
     with pytest.raises(ValueError):
-        gpu_ctx.merkle4_forest_device(tag, d, 1, 12, roots, None, arity=2)  # 12 is not 2^k
+        gpu_ctx.merkle4_forest_device(tag, d, 1, 12, torch.empty((1, 4), dtype=torch.int64, device="cuda:0"), None, arity=2)  # 12 is not 2^k
