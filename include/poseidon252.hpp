@@ -305,7 +305,7 @@ class Comm {
 };
 
 // Roots of the leaves.size() / leaves_per_tree independent complete trees stored tree-major in HOST memory
-// (p252_merkle4_forest: whole trees stream through the staging lanes, one forest build per chunk)
+// (p252_merkle4_forest: the first level is hashed while the leaves stream in through the staging lanes, the upper levels once)
 inline std::vector<BlsScalar> merkle4_forest(const std::vector<BlsScalar>& leaves, std::size_t leaves_per_tree,
                                              Context& ctx = Context::default_context()) {
     if (leaves_per_tree == 0 || leaves.size() % leaves_per_tree) throw std::invalid_argument("merkle4_forest: not whole trees");

@@ -220,9 +220,9 @@ int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
  * tree t's nodes of that level at t * 4^(k-l) within it.  Asynchronous on hip_stream. */
 int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
                                void* d_roots, void* d_levels, void* hip_stream);
-/* the same from HOST leaves (pageable memory is fine), roots to host memory: whole trees stream through the context's staging lanes
- * chunk by chunk (32 MiB of leaves each; a forest build per chunk, its inner levels in device-only scratch), so the PCIe copy of
- * one chunk overlaps the hashing of another; synchronous */
+/* the same from HOST leaves (pageable memory is fine), roots to host memory: the first level — three quarters of the work — is hashed
+ * chunk by chunk while the leaves stream in through the context's staging lanes (the leaves are never resident as a whole), the
+ * upper levels then run once, one launch per level across all trees; synchronous */
 int p252_merkle4_forest(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_trees, size_t leaves_per_tree,
                         uint64_t* roots);
 /* the same for arity 2 (Domain::Merkle2 nodes; pass the Merkle2 tag): leaves_per_tree = 2^k, p252_merkle2_levels_len per tree */

@@ -148,7 +148,6 @@ void p252_destroy(p252_ctx* ctx) {
             if (sl.h_out) (void)hipHostFree(sl.h_out);
             if (sl.d_in) (void)hipFree(sl.d_in);
             if (sl.d_out) (void)hipFree(sl.d_out);
-            if (sl.d_scr) (void)hipFree(sl.d_scr);
             if (sl.done) (void)hipEventDestroy(sl.done);
         }
     }
@@ -424,7 +423,7 @@ static int staging_lanes_per_ctx(size_t n_ctx) {
 // of ins[a] / outs[a] (256-byte aligned).  `outs` may be empty (results stay on the device: the launch writes them itself).
 template <class Launch>
 static int staged_run(p252_ctx* ctx, size_t n, size_t chunk, const std::vector<HostSpan>& ins, const std::vector<HostSpan>& outs,
-                      Launch&& launch, size_t scratch_stride = 0) {
+                      Launch&& launch) {
     const size_t n_chunks = (n + chunk - 1) / chunk;
     const int lanes_wanted = ctx->lane_budget > 0 ? ctx->lane_budget : staging_lanes_wanted();
     const int n_lanes = (int)(n_chunks < (size_t)lanes_wanted ? n_chunks : (size_t)lanes_wanted);
@@ -462,13 +461,6 @@ static int staged_run(p252_ctx* ctx, size_t n, size_t chunk, const std::vector<H
                 HIP_TRY(ctx, hipMalloc(&S.d_out, out_chunk_b));
                 S.out_cap = out_chunk_b;
             }
-            if (S.scr_cap < chunk * scratch_stride) {  // device-only scratch per chunk, handed to launch as d_out[outs.size()]
-                if (S.d_scr) (void)hipFree(S.d_scr);
-                S.d_scr = nullptr;
-                S.scr_cap = 0;
-                HIP_TRY(ctx, hipMalloc(&S.d_scr, chunk * scratch_stride));
-                S.scr_cap = chunk * scratch_stride;
-            }
         }
     }
     std::atomic<size_t> next{0};
@@ -498,7 +490,7 @@ static int staged_run(p252_ctx* ctx, size_t n, size_t chunk, const std::vector<H
             return true;
         };
         std::vector<const void*> d_in(ins.size());
-        std::vector<void*> d_out(outs.size() + 1);
+        std::vector<void*> d_out(outs.size());
         int k = 0;
         for (;;) {
             const size_t c = next.fetch_add(1);
@@ -515,7 +507,6 @@ static int staged_run(p252_ctx* ctx, size_t n, size_t chunk, const std::vector<H
                 d_in[a] = d;
             }
             for (size_t a = 0; a < outs.size(); ++a) d_out[a] = static_cast<char*>(S.d_out) + out_off[a];
-            d_out[outs.size()] = S.d_scr;
             e = launch(d_in.data(), d_out.data(), off, cnt, L.st);
             if (e != hipSuccess) return bad("kernel launch", e);
             for (size_t a = 0; a < outs.size(); ++a) {
@@ -720,9 +711,11 @@ int p252_merkle2_tree(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leav
     return merkle_tree_host(ctx, 2, tag, leaves, n_leaves, root, levels);
 }
 
-// Forest from HOST leaves (pageable memory is fine): whole trees stream through the staging lanes chunk by chunk — the leaves of
-// a chunk in, one forest build per chunk on the lane's stream (its inner levels in device-only scratch of the slot), the
-// chunk's roots out — so the PCIe copy of chunk c + 1 overlaps the hashing of chunk c.  Trees are independent: no exchange.
+// Forest from HOST leaves (pageable memory is fine).  Large forests: the FIRST level — three quarters of all permutations — is
+// hashed chunk by chunk while the leaves stream in through the staging lanes (8 MiB chunks; its nodes stay on the device, the
+// leaves are never resident as a whole), then the upper levels run ONCE, one launch per level across all trees, so their
+// latency-bound launches are paid once per forest and not once per chunk (a first version that built a whole forest per
+// 32-MiB chunk ran at 2.5e8 perm/s: every chunk paid the five narrow levels).  Trees are independent: no exchange.
 int p252_merkle4_forest(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, size_t n_trees, size_t leaves_per_tree, uint64_t* roots) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (n_trees == 0) return P252_OK;
@@ -730,30 +723,22 @@ int p252_merkle4_forest(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* le
     if (n_trees > (SIZE_MAX / 32) / leaves_per_tree) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_forest: size overflow");
     if (!tag || !leaves || !roots) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_forest: NULL buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t tree_b = leaves_per_tree * 32, lv_b = levels_len(leaves_per_tree, 4) * 32;
-    // a chunk is a forest build of its own — log4(leaves_per_tree) launches, the upper ones bound by one wave's latency — so chunks
-    // are four times the digest pipeline's (P252_HOST_CHUNK_MB x 4, default 32 MiB): 256 trees of 4^6 leaves hash in ~1.2 ms
-    static const size_t chunk_bytes_target = [] {
-        const char* e = std::getenv("P252_HOST_CHUNK_MB");
-        const int mb = e ? std::atoi(e) : 8;
-        return (size_t)(mb < 1 ? 1 : (mb > 64 ? 64 : mb)) << 22;
-    }();
-    size_t chunk = chunk_bytes_target / tree_b;  // trees per chunk
-    if (chunk < 1) chunk = 1;
-    if (n_trees >= 2 * chunk && leaves_per_tree > 1) {
-        return staged_run(ctx, n_trees, chunk, {{reinterpret_cast<const char*>(leaves), nullptr, tree_b}}, {{nullptr, reinterpret_cast<char*>(roots), 32}},
-                          [&](const void* const* d_in, void* const* d_out, size_t, size_t cnt, hipStream_t st) {
-                              return forest_device(ctx, 4, tag, d_in[0], cnt, leaves_per_tree, d_out[0], d_out[1], st) == P252_OK ? hipSuccess : hipErrorUnknown;
-                          },
-                          lv_b ? lv_b : 32);
+    const size_t n_leaves = n_trees * leaves_per_tree, n_l1 = n_leaves / 4;
+    const size_t chunk_nodes = (((size_t)8 << 20) / (4 * 32)) & ~(size_t)255;  // 8 MiB of leaves per chunk, as the tree's host path
+    int rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, n_trees * 32);
+    if (rc) return rc;
+    if (leaves_per_tree >= 4 && n_l1 >= 4 * chunk_nodes && !is_pinned(leaves)) {
+        rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, n_l1 * 32);
+        if (rc) return rc;
+        rc = hash_batch_staged(ctx, tag, leaves, 4, 1, nullptr, n_l1, chunk_nodes, static_cast<char*>(ctx->d_in));
+        if (rc) return rc;
+        rc = forest_device(ctx, 4, tag, ctx->d_in, n_trees, leaves_per_tree / 4, ctx->d_out, nullptr, nullptr);
+    } else {  // small forest (or page-locked leaves: the DMA runs at PCIe speed anyway): one upload, one build
+        rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, n_leaves * 32);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpy(ctx->d_in, leaves, n_leaves * 32, hipMemcpyHostToDevice));
+        rc = forest_device(ctx, 4, tag, ctx->d_in, n_trees, leaves_per_tree, ctx->d_out, nullptr, nullptr);
     }
-    // small forest: one upload, one build, one download
-    int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, n_trees * tree_b);
-    if (rc) return rc;
-    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, n_trees * 32);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(ctx->d_in, leaves, n_trees * tree_b, hipMemcpyHostToDevice));
-    rc = forest_device(ctx, 4, tag, ctx->d_in, n_trees, leaves_per_tree, ctx->d_out, nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpy(roots, ctx->d_out, n_trees * 32, hipMemcpyDeviceToHost));
     return P252_OK;

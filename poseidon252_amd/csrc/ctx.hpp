@@ -30,8 +30,7 @@ struct p252_ctx {
         void* h_out = nullptr;
         void* d_in = nullptr;
         void* d_out = nullptr;
-        void* d_scr = nullptr;  // device-only scratch of a chunk (staged_run's scratch_stride: the inner levels of a forest chunk)
-        size_t in_cap = 0, out_cap = 0, scr_cap = 0;
+        size_t in_cap = 0, out_cap = 0;
         hipEvent_t done = nullptr;
     };
     struct Lane {  // one worker thread + stream, double-buffered: the host copy of chunk c+1 overlaps the DMA / kernel of chunk c

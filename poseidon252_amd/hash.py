@@ -223,8 +223,8 @@ class Context:
                                                          self._stream()))
 
     def merkle4_forest(self, tag, leaves, leaves_per_tree):
-        """host leaves (numpy, pageable is fine) -> roots (n_trees, 4) numpy: p252_merkle4_forest streams whole trees through the
-        staging lanes, one forest build per chunk"""
+        """host leaves (numpy, pageable is fine) -> roots (n_trees, 4) numpy: p252_merkle4_forest hashes the first level while the
+        leaves stream in through the staging lanes, then the upper levels once across all trees"""
         tag = _as_scalars(tag).reshape(4)
         lv = _as_scalars(leaves).reshape(-1, 4)
         if leaves_per_tree < 1 or lv.shape[0] % leaves_per_tree:

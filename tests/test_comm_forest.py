@@ -140,8 +140,9 @@ def test_forest_roots_equal_per_tree_oracle_roots(gpu_ctx, oracle_mod, n_trees, 
     torch.cuda.synchronize()
     roots = roots.cpu().numpy().view(np.uint64)
     levels = levels.cpu().numpy().view(np.uint64)
-    # host leaves, roots only: p252_merkle4_forest — whole trees through the staging lanes, a forest build per chunk (1,024 x 4^6 and
-    # 3,001 x 4^5 leaves are several chunks, the last one ragged; the small shapes take the one-upload path)
+    # host leaves, roots only: p252_merkle4_forest — the first level hashed chunk by chunk while the leaves stream in through the
+    # staging lanes, the upper levels once across all trees (1,024 x 4^6 and 3,001 x 4^5 leaves are several chunks, the last one
+    # ragged; the small shapes take the one-upload path)
     roots2 = P.merkle4_forest(lv, per, tag=tag, ctx=gpu_ctx)
     assert np.array_equal(roots, roots2)
     idx = sorted(set([0, n_trees - 1] + list(range(0, n_trees, max(1, n_trees // 40)))))
@@ -215,4 +216,4 @@ def test_merkle2_forest_equals_per_tree_oracle_roots(gpu_ctx, oracle_mod, n_tree
             off_tree += width
             width //= 2
     with pytest.raises(ValueError):
-        gpu_ctx.merkle4_forest_device(tag, d, 1, 12, torch.empty((1, 4), dtype=torch.int64, device="cuda:0"), None, arity=2)  # 12 is not 2^k
+        gpu_ctx.merkle4_forest_device(tag, d, 1, 3, torch.empty((1, 4), dtype=torch.int64, device="cuda:0"), None, arity=2)  # 3 is not 2^k
