@@ -49,7 +49,8 @@ if "--long" in sys.argv:
     from poseidon252_amd import encryption as E
     minutes = float(sys.argv[sys.argv.index("--long") + 1]) if len(sys.argv) > sys.argv.index("--long") + 1 else 5.0
     counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0, "tree updates": 0,
-              "forest trees": 0, "sharded-tree leaves (RCCL, one rank)": 0}
+              "forest trees": 0, "sharded-tree leaves (RCCL, one rank)": 0,
+              "openings extracted on the device": 0}
     from poseidon252_amd import comm as C
     comm_ctx = P.Context(0)
     comm1 = C.Comm.create_rank(comm_ctx, 0, 1, lambda b: b)  # the library's RCCL communicator on the real backend (round 4)
@@ -60,7 +61,7 @@ if "--long" in sys.argv:
     while time.time() - t0 < 60 * minutes:
         it += 1
         seed = int(rng.integers(1, 1 << 30))
-        kind = it % 11
+        kind = it % 12
         n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 8193)), int(rng.integers(8193, 20000))]))
         if kind == 0:
             n = min(n, 12000)
@@ -164,6 +165,23 @@ if "--long" in sys.argv:
                     assert np.array_equal(levels[off_f + t * width:off_f + (t + 1) * width], o_levels[off_t:off_t + width]), ("forest levels", arity, per, n_trees, t, width, seed)
                     off_f, off_t, width = off_f + n_trees * width, off_t + width, width // arity
             counts["forest trees"] += n_trees
+        elif kind == 11:  # openings of a stored tree extracted on the device: against the host bookkeeping, then re-hashed to the root
+            import torch
+            from poseidon252_amd import merkle
+            leaves_n = int(rng.choice([int(rng.integers(1, 3000)), 4 ** int(rng.integers(0, 9)), int(rng.integers(3000, 90000))]))
+            k = int(rng.integers(1, 4000))
+            lv = oracle.fill_random(seed, leaves_n)
+            d_lv = torch.from_numpy(lv.view(np.int64).copy()).cuda()
+            d_root, d_levels = P.merkle4_tree(d_lv, tag=mtag, ctx=ctx, want_levels=True)
+            idx = rng.integers(0, leaves_n, size=k).astype(np.int32)
+            out, sib, pos, depth = ctx.merkle4_openings_device(d_lv, leaves_n, d_levels, torch.from_numpy(idx).cuda(), k, check=True)
+            roots = torch.empty((k, 4), dtype=torch.int64, device="cuda")
+            ctx.merkle4_path_batch_device(mtag, out, sib, pos, depth, roots, k)
+            torch.cuda.synchronize()
+            h_sib, h_pos = merkle.merkle4_openings(lv, d_levels.cpu().numpy().view(np.uint64)[:oracle.levels_total(leaves_n)], idx)
+            assert np.array_equal(sib.cpu().numpy().view(np.uint64).reshape(h_sib.shape), h_sib) and np.array_equal(pos.cpu().numpy().reshape(h_pos.shape), h_pos), ("openings extract", leaves_n, k, seed)
+            assert bool((roots == d_root.view(1, 4)).all()) and np.array_equal(d_root.cpu().numpy().view(np.uint64), oracle.merkle4_tree(mtag, lv)[0]), ("openings rehash", leaves_n, k, seed)
+            counts["openings extracted on the device"] += k
         elif kind == 10:  # subtree -> ncclAllGather of the roots on the stream -> top levels, inside the library
             import torch
             leaves_n = 4 ** int(rng.integers(0, 10))

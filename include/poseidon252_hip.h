@@ -56,7 +56,7 @@ extern "C" {
  *   5  + p252_abi_version, p252_merkle4_update_checked_device, p252_clock_probe_device, p252_staging_lanes; out-of-range
  *      indices of p252_merkle4_update_device are skipped (were undefined behaviour)
  *   6  + the RCCL communicator (p252_comm_*), p252_merkle4_tree_sharded_device, p252_merkle4_tree_multi_device_resident,
- *      p252_merkle4_forest[_device], p252_merkle2_forest_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
+ *      p252_merkle4_forest[_device], p252_merkle2_forest_device, p252_merkle4_openings_device, p252_merkle4_depth, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
  *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on) */
 #define P252_ABI_VERSION 6
 
@@ -209,6 +209,16 @@ int p252_encrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
                               const void* d_nonces, size_t len, void* d_ciphers, size_t n, void* hip_stream);
 int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4], const void* d_ciphers, const void* d_secrets,
                               const void* d_nonces, size_t len, void* d_messages, void* d_ok, size_t n, void* hip_stream);
+
+/* Openings of a STORED tree, extracted on the device (no hashing; HBM-bound data movement): d_leaves[n_leaves] and d_levels as
+ * p252_merkle4_tree_device filled them (all levels, bottom-up); d_indices = k leaf positions (uint32, device).  Writes, in exactly
+ * the layout p252_merkle4_path_batch_device reads: d_leaves_out[k] (the leaves at those positions), d_siblings[k][depth][3],
+ * d_positions[k][depth] with depth = p252_merkle4_depth(n_leaves); missing siblings of a ragged level are the zero scalar
+ * (hash.rs:22-26).  A position >= n_leaves yields an all-zero opening and is counted in *d_n_bad (uint32, device; may be NULL).
+ * Re-hashing the result with p252_merkle4_path_batch_device gives the tree's root for every valid position.  Asynchronous. */
+size_t p252_merkle4_depth(size_t n_leaves);
+int p252_merkle4_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
+                                 void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream);
 
 /* A FOREST of n_trees independent complete arity-4 trees of leaves_per_tree = 4^k leaves each (the downstream poseidon-merkle
  * shape, AGENTS.md:62-66: many small trees), tree-major in d_leaves.  Level l of all trees is one array of

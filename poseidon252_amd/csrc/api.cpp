@@ -18,6 +18,7 @@
 #include "ctx.hpp"
 #include "hades29.hpp"
 #include "kernels.h"
+#include "openings.h"
 #include "tables.hpp"
 #include "_gen/assets.inc"
 
@@ -870,6 +871,34 @@ int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const v
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_merkle4_path(ctx->d_tab, tag_arg(tag), d_leaves, d_siblings, d_positions, (unsigned)depth,
                                      d_roots, n, (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+// depth of the arity-4 tree over n_leaves = number of levels above the leaves (a 4^k-leaf tree: k; a single leaf: 0)
+size_t p252_merkle4_depth(size_t n_leaves) {
+    size_t d = 0;
+    for (size_t c = n_leaves; c > 1; c = (c + 3) / 4) ++d;
+    return d;
+}
+
+// Openings of a STORED tree, extracted on the device (openings.hip: pure data movement): for each of the k leaf positions the
+// leaf, the three siblings per level and the position bytes, in exactly the layout p252_merkle4_path_batch_device takes — build
+// (all levels) -> extract -> verify never leaves the GPU.
+int p252_merkle4_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
+                                 void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (k == 0) return P252_OK;
+    if (n_leaves == 0 || n_leaves > 0xffffffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: n_leaves must be in 1 .. 2^32 - 1 (positions are uint32)");
+    const size_t depth = p252_merkle4_depth(n_leaves);
+    if (!d_leaves || !d_indices || !d_leaves_out || (depth && (!d_levels || !d_siblings || !d_positions)))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: NULL buffer");
+    if (misaligned(d_leaves) || misaligned(d_levels) || misaligned(d_leaves_out) || misaligned(d_siblings)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
+    if ((reinterpret_cast<uintptr_t>(d_indices) & 3u) || (reinterpret_cast<uintptr_t>(d_n_bad) & 3u))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: indices / counter must be 4-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (d_n_bad) HIP_TRY(ctx, hipMemsetAsync(d_n_bad, 0, 4, st));
+    HIP_TRY(ctx, launch_merkle4_openings(d_leaves, n_leaves, d_levels, d_indices, k, (unsigned)depth, d_leaves_out, d_siblings, d_positions, d_n_bad, st));
     return P252_OK;
 }
 

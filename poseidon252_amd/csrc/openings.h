@@ -1,0 +1,18 @@
+// openings.h — launch interface of openings.hip (extraction of Merkle openings from a stored tree: pure data movement, no hashing).
+// Kept apart from kernels.h / kernels.hip: those are the HASHING kernels, whose source digest the committed counter passes and ISA
+// counts under profiles/ are keyed to (bench.py KERNEL_SOURCES).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace p252 {
+
+// k openings out of a tree stored as leaves[n_leaves] + levels (bottom-up concatenation, as the tree builder writes them):
+// leaves_out[k], siblings[k][depth][3], positions[k][depth] — the arrays launch_merkle4_path takes.  index[i] >= n_leaves: the
+// opening is all zeros and *n_bad (may be null) is incremented.
+hipError_t launch_merkle4_openings(const void* leaves, size_t n_leaves, const void* levels, const void* index, size_t k, unsigned depth,
+                                   void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st);
+
+}  // namespace p252

@@ -302,6 +302,26 @@ class Context:
                                                         roots.ctypes.data_as(_u64p), n))
         return roots
 
+    def merkle4_openings_device(self, d_leaves, n_leaves, d_levels, d_indices, k, check=False):
+        """openings of a stored tree, extracted on the device (p252_merkle4_openings_device): d_indices = k leaf positions (int32 /
+        uint32 torch tensor).  Returns (d_leaves_out (k,4), d_siblings (k,depth,3,4), d_positions (k,depth) uint8, depth) — what
+        merkle4_path_batch_device takes.  check=True: raises if a position lies outside the tree (they yield zero openings)."""
+        import torch
+        assert d_leaves.is_cuda and d_indices.is_cuda and d_indices.element_size() == 4 and d_indices.is_contiguous()
+        depth = int(_lib.lib().p252_merkle4_depth(n_leaves))
+        assert self._nbytes(d_leaves) >= n_leaves * 32 and (depth == 0 or self._nbytes(d_levels) >= _lib.lib().p252_merkle4_levels_len(n_leaves) * 32)
+        dev = d_leaves.device
+        out = torch.empty((k, 4), dtype=torch.int64, device=dev)
+        sib = torch.empty((k, depth, 3, 4), dtype=torch.int64, device=dev)
+        pos = torch.empty((k, depth), dtype=torch.uint8, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._check(_lib.lib().p252_merkle4_openings_device(self._h, d_leaves.data_ptr(), n_leaves, d_levels.data_ptr() if depth else None,
+                                                             d_indices.data_ptr(), k, out.data_ptr(), sib.data_ptr() if depth else None,
+                                                             pos.data_ptr() if depth else None, bad.data_ptr(), self._stream()))
+        if check and int(bad.item()):
+            raise ValueError("merkle4_openings: %d position(s) outside the tree" % int(bad.item()))
+        return out, sib, pos, depth
+
     def merkle4_path_batch_device(self, tag, d_leaves, d_siblings, d_positions, depth, d_roots, n):
         tag = _as_scalars(tag).reshape(4)
         assert d_leaves.is_cuda and d_roots.is_cuda and self._nbytes(d_leaves) >= n * 32 and self._nbytes(d_roots) >= n * 32
