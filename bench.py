@@ -22,6 +22,8 @@ runs this one command:
                       level across all trees — the downstream poseidon-merkle shape; no narrow levels left to wait for)
   secondary.sponge42  BASELINE configs[3]: Domain::Other sponge, 2^20 messages x 42 scalars -> 5 outputs per GPU
   secondary.openings  SURVEY §8 f3: 2^20 Merkle4 openings of depth 12 per GPU (branch re-hash, k_merkle4_path_lines)
+  secondary.extract   SURVEY §8 f3: 2^20 openings of depth 12 EXTRACTED from a stored 2^24-leaf tree per GPU (k_merkle4_openings: data movement,
+                      no hashing) — the one workload priced against the HBM roofline ("bound": "hbm", GB/s against 8 TB/s)
   secondary.encrypt   SURVEY §8 f4: 2^20 encryptions of 2-scalar messages per GPU (k_crypt; construction unpinned)
 (--no-secondary skips them; --workload X makes X the primary and runs no secondary; --log2n scales the primary.)
 
@@ -53,7 +55,7 @@ MACS_PER_PERM_REFERENCE = 256_000      # 2000 field mults x 128 32x32->64 MACs (
 BYTES_PER_PERM = {"merkle4_digests": 160.0, "tree": 96.0, "forest": (4096 * 32 + 32) / 1365.0, "sponge42": 1504.0 / 12.0,
                   "openings": (32 + 12 * 96 + 12 + 32) / 12.0,  # leaf + 12 x 3 siblings + 12 position bytes + root
                   "encrypt": (5 * 32 + 3 * 32) / 2.0}             # 2 message + 2 secret + 1 nonce scalars in, 3 cipher scalars out
-KERNEL_OF = {"merkle4_digests": "k_merkle4", "tree": "k_merkle4", "forest": "k_merkle4", "sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}
+KERNEL_OF = {"merkle4_digests": "k_merkle4", "tree": "k_merkle4", "forest": "k_merkle4", "extract": "k_merkle4_openings", "sponge42": "k_sponge", "openings": "k_merkle4_path", "encrypt": "k_crypt"}
 # VALU issue peak of the chip (the binding roofline): a wave64 v_mad_i64_i32 occupies its SIMD for 4
 # cycles, so 1024 SIMDs x clock / 4 wave-instructions/s; x 64 lanes = lane-MACs/s.  At the nominal 2.4 GHz that is
 # 614.4 G wave-instructions/s = 39.3 T lane-MACs/s — `peak`.  The clock the chip actually holds under this load is lower
@@ -103,7 +105,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # the clocks need ~10 launches (25 ms) to ramp from idle
-    ap.add_argument("--workload", default=None, choices=["merkle4_digests", "tree", "forest", "sponge42", "openings", "encrypt"],
+    ap.add_argument("--workload", default=None, choices=["merkle4_digests", "tree", "forest", "sponge42", "openings", "encrypt", "extract"],
                     help="primary workload (default merkle4_digests = BASELINE configs[1], followed by the secondary workloads)")
     ap.add_argument("--log2n", type=int, default=None, help="log2 of units per GPU per step of the primary (default: 20; tree: 24 leaves)")
     ap.add_argument("--no-secondary", action="store_true", help="do not time the secondary workloads (tree, sponge42)")
@@ -421,6 +423,20 @@ def make_workload(E, wl, log2n):
         W.name = ("forest of %d independent arity-4 Merkle trees of 4^%d leaves per GPU (2^%d leaves; p252_merkle4_forest_device: one launch per level "
                   "across all trees; the poseidon-merkle shape, AGENTS.md:62-66)" % (W.n_trees, 6 if W.per_tree == 4 ** 6 else 2, log2n))
         W.wake = 6
+    elif wl == "extract":
+        # the path's one HBM-bound kernel with a workload of its own: 2^log2n openings extracted (no hashing) out of a STORED tree of
+        # 2^(log2n + 4) leaves — units are (opening, level) records of 96 sibling bytes; priced against the HBM roofline
+        log2n = log2n or 20
+        n = 1 << log2n
+        hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx)
+        W.tree_leaves = n << 4
+        W.depth = (log2n + 4 + 1) // 2  # levels above 2^(log2n + 4) leaves
+        in_scalars, W.perms_per_step = W.tree_leaves, n * W.depth
+        W.unit = "opening levels/s"
+        W.bytes_per_unit = 96.0 + 96.0 + 1.0 + (64.0 + 4.0) / W.depth  # siblings read + written, position byte; per opening: leaf in + out, index
+        W.name = ("2^%d openings of depth %d extracted on the device from a stored 2^%d-leaf tree (p252_merkle4_openings_device: data movement "
+                  "only, SURVEY §8 f3) — HBM roofline" % (log2n, W.depth, log2n + 4))
+        W.wake = 6
     elif wl == "encrypt":
         log2n = log2n or 20
         n = 1 << log2n
@@ -502,6 +518,14 @@ def make_workload(E, wl, log2n):
         d_out = torch.empty((W.n_trees, 4), dtype=torch.int64, device=dev)
         W.step = lambda: ctx.merkle4_forest_device(tag, d_in, W.n_trees, W.per_tree, d_out)
         W.step()  # (context-owned level scratch, outside the timed region)
+    elif wl == "extract":
+        W.d_root, W.d_levels = P.merkle4_tree(d_in, tag=tag, ctx=ctx, want_levels=True)  # the stored tree (built once, outside any timed region)
+        d_idx = torch.randint(0, W.tree_leaves, (n,), dtype=torch.int32, device=dev, generator=g)  # random paths: the gather's worst case
+        d_out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        W.d_sib = torch.empty((n, W.depth, 3, 4), dtype=torch.int64, device=dev)
+        W.d_pos = torch.empty((n, W.depth), dtype=torch.uint8, device=dev)
+        W.d_bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        W.step = lambda: ctx.merkle4_openings_device(d_in, W.tree_leaves, W.d_levels, d_idx, n, out=(d_out, W.d_sib, W.d_pos, W.d_bad))
     elif wl == "encrypt":
         d_out = torch.empty((n, 3, 4), dtype=torch.int64, device=dev)
         d_msgs, d_secrets, d_nonces = d_in[:2 * n], d_in[2 * n:4 * n], d_in[4 * n:]
@@ -544,6 +568,11 @@ def make_workload(E, wl, log2n):
             again = P.merkle4_tree(gathered.to(dev).view(world, 4).contiguous(), tag=tag, ctx=ctx)
             torch.cuda.synchronize()
             return bool(torch.equal(top, ref) and torch.equal(again, W.d_top))
+        if wl == "extract":  # every extracted opening re-hashes to the stored tree's root; no position was out of range
+            roots = torch.empty((n, 4), dtype=torch.int64, device=dev)
+            ctx.merkle4_path_batch_device(tag, d_out, W.d_sib, W.d_pos, W.depth, roots, n)
+            torch.cuda.synchronize()
+            return bool((roots == W.d_root.view(1, 4)).all()) and int(W.d_bad.item()) == 0
         if wl == "forest":  # a few trees built on their own by the single-tree entry point
             pick = sorted(set([0, W.n_trees // 3, W.n_trees - 1]))
             alone = torch.stack([P.merkle4_tree(d_in[t * W.per_tree:(t + 1) * W.per_tree], tag=tag, ctx=ctx) for t in pick])
@@ -577,6 +606,10 @@ def make_workload(E, wl, log2n):
             sub = min(n, 1 << 12)
             got = P.merkle4_tree(d_in[:sub].contiguous(), tag=tag, ctx=ctx).cpu().numpy().view(np.uint64)
             return ("tree", tag, d_in[:sub].cpu().numpy().view(np.uint64), None, None, got)
+        if wl == "extract":  # a sample of the extracted openings: the oracle re-hashes them and must arrive at the GPU tree's root
+            idx = torch.arange(0, n, max(1, n // 128), device=dev)
+            return ("paths", tag, (d_out[idx].cpu().numpy().view(np.uint64), W.d_sib[idx].cpu().numpy().view(np.uint64), W.d_pos[idx].cpu().numpy()),
+                    None, None, W.d_root.cpu().numpy().view(np.uint64).reshape(1, 4).repeat(idx.numel(), axis=0))
         if wl == "forest":  # four trees of what was just timed, leaves and roots
             pick = sorted(set([0, W.n_trees // 2, W.n_trees - 2, W.n_trees - 1]))
             leaves = torch.stack([d_in[t * W.per_tree:(t + 1) * W.per_tree] for t in pick]).cpu().numpy().view(np.uint64)
@@ -659,7 +692,33 @@ def sysfs_sclk_mhz(torch, local_rank):
         return None
 
 
+def roofline_hbm_of(W, launch_ms, clk_before, clk_after):
+    """the contract's HBM shape for a workload whose kernel moves bytes and computes nothing (extract): achieved = ALGORITHMIC bytes
+    per launch / mean launch time (HIP events on the launch stream) against the 8 TB/s HBM3E peak; traffic = HBM bytes per launch
+    from the committed FETCH_SIZE x 2 + WRITE_SIZE counter passes of that kernel (a random gather fetches whole 128-byte lines for
+    the 96 bytes it uses: ratio ~1.17 by construction)"""
+    k_ms = float(np.mean(launch_ms))
+    alg = W.bytes_per_unit * W.perms_per_step
+    gbps = alg / (k_ms * 1e-3) / 1e9
+    kern = KERNEL_OF[W.key]
+    d = pmc_profile(kern)
+    traffic = None
+    if d and "hbm_bytes_per_launch" in d and not d["stale"]:
+        traffic = d["hbm_bytes_per_launch"] * W.perms_per_step / d["units_per_launch"]
+    clocks = [c["shader_ghz"] for c in (clk_before, clk_after) if c]
+    return {"bound": "hbm", "kernel": kern, "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+            "traffic": traffic, "traffic_algorithmic_bytes": alg, "traffic_ratio": (traffic / alg) if traffic else None,
+            "traffic_source": d["source"] if d else None,
+            "algorithmic_bytes_per_unit": W.bytes_per_unit, "units_per_launch": W.perms_per_step,
+            "launch_ms_mean": k_ms, "launch_ms_min": float(np.min(launch_ms)),
+            "clock_ghz_measured": float(np.mean(clocks)) if clocks else None,
+            "note": "HBM-bound data movement (no arithmetic): algorithmic bytes = per (opening, level) 96 sibling bytes read + 96 written + "
+                    "1 position byte, per opening the leaf in and out and its index; random positions (a gather of one 128-byte line per record)"}
+
+
 def roofline_of(W, launch_ms, clk_before, clk_after, sclk_sysfs=None):
+    if W.key == "extract":
+        return roofline_hbm_of(W, launch_ms, clk_before, clk_after)
     wl, n = W.key, W.n
     k_ms = float(np.mean(launch_ms))
     per_gpu_rate = W.perms_per_step / (k_ms * 1e-3)
@@ -795,7 +854,7 @@ def main():
 
     primary_key = args.workload or "merkle4_digests"
     # BASELINE configs[2] / [3] (configs[4] at 8 ranks), then the SURVEY §8(f) rows that have kernels of their own
-    secondary_keys = [] if (args.workload or args.no_secondary) else ["tree", "forest", "sponge42", "openings", "encrypt"]
+    secondary_keys = [] if (args.workload or args.no_secondary) else ["tree", "forest", "sponge42", "openings", "encrypt", "extract"]
     sclk0 = sysfs_sclk_mhz(torch, local_rank)
 
     def measure(key, log2n, steps, warmup):
@@ -817,8 +876,9 @@ def main():
         total_perms = getattr(W, "job_units_per_step", W.perms_per_step * world) * args.steps
         roofline = roofline_of(W, launch_ms, cb, ca, {"idle_before_run": sclk0, "after_timed_region": sysfs_sclk_mhz(torch, local_rank)})
         line = {
-            "metric": "Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact",
-            "value": total_perms / elapsed, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("Poseidon width-5 permutations/s (= Merkle4 digests/s), bit-exact" if W.key != "extract" else
+                       "Merkle opening levels extracted/s (data movement, no hashing; --workload extract)"),
+            "value": total_perms / elapsed, "unit": getattr(W, "unit", "permutations/s"), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             # every rank's own time per step up to its last launch completing (before the closing barrier): min / max = balance
             "ms_per_step_rank_min": min(W.rank_ms_per_step), "ms_per_step_rank_max": max(W.rank_ms_per_step), "ms_per_step_per_rank": W.rank_ms_per_step,
@@ -835,8 +895,10 @@ def main():
                        "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
             "roofline": roofline,
             # the same kernel priced against the HBM roofline in the contract's shape (NOT the binding bound here)
-            "roofline_hbm": {"bound": "hbm", "achieved": roofline["hbm"]["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": roofline["hbm"]["frac"], "traffic": roofline["traffic"], "traffic_ratio": roofline["traffic_ratio"]},
+            "roofline_hbm": ({"bound": "hbm", "achieved": roofline["hbm"]["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                              "frac": roofline["hbm"]["frac"], "traffic": roofline["traffic"], "traffic_ratio": roofline["traffic_ratio"]}
+                             if roofline["bound"] != "hbm" else
+                             {k: roofline[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio")}),
             "self_consistency_ok": self_ok,
             "setup": {"wake_up_launches": W.wake,
                       "note": "untimed launches of the same step before the W warm-up steps: brings an idle GPU's clocks to steady state; "
@@ -888,7 +950,7 @@ def main():
                 "units_whole_job_per_step": getattr(W2, "job_units_per_step", W2.perms_per_step * world),
                 "value": getattr(W2, "job_units_per_step", W2.perms_per_step * world) * s_steps / el2,
                 "ms_per_step_rank_min": min(W2.rank_ms_per_step), "ms_per_step_rank_max": max(W2.rank_ms_per_step), "ms_per_step_per_rank": W2.rank_ms_per_step,
-                "unit": "permutations/s", "n_gpus": world,
+                "unit": getattr(W2, "unit", "permutations/s"), "n_gpus": world,
                 "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                 "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                 "exchange": ("all-gather of %d x 32-byte subtree roots per step" % world) if (key == "tree" and dist.is_initialized()) else None,

@@ -302,19 +302,24 @@ class Context:
                                                         roots.ctypes.data_as(_u64p), n))
         return roots
 
-    def merkle4_openings_device(self, d_leaves, n_leaves, d_levels, d_indices, k, check=False):
+    def merkle4_openings_device(self, d_leaves, n_leaves, d_levels, d_indices, k, check=False, out=None):
         """openings of a stored tree, extracted on the device (p252_merkle4_openings_device): d_indices = k leaf positions (int32 /
         uint32 torch tensor).  Returns (d_leaves_out (k,4), d_siblings (k,depth,3,4), d_positions (k,depth) uint8, depth) — what
-        merkle4_path_batch_device takes.  check=True: raises if a position lies outside the tree (they yield zero openings)."""
+        merkle4_path_batch_device takes.  check=True: raises if a position lies outside the tree (they yield zero openings);
+        out = (d_leaves_out, d_siblings, d_positions, d_n_bad) to write into caller-owned tensors (no allocation per call)."""
         import torch
         assert d_leaves.is_cuda and d_indices.is_cuda and d_indices.element_size() == 4 and d_indices.is_contiguous()
         depth = int(_lib.lib().p252_merkle4_depth(n_leaves))
         assert self._nbytes(d_leaves) >= n_leaves * 32 and (depth == 0 or self._nbytes(d_levels) >= _lib.lib().p252_merkle4_levels_len(n_leaves) * 32)
         dev = d_leaves.device
-        out = torch.empty((k, 4), dtype=torch.int64, device=dev)
-        sib = torch.empty((k, depth, 3, 4), dtype=torch.int64, device=dev)
-        pos = torch.empty((k, depth), dtype=torch.uint8, device=dev)
-        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        if out is not None:
+            out, sib, pos, bad = out
+            assert self._nbytes(out) >= k * 32 and self._nbytes(sib) >= k * depth * 96 and self._nbytes(pos) >= k * depth and self._nbytes(bad) >= 4
+        else:
+            out = torch.empty((k, 4), dtype=torch.int64, device=dev)
+            sib = torch.empty((k, depth, 3, 4), dtype=torch.int64, device=dev)
+            pos = torch.empty((k, depth), dtype=torch.uint8, device=dev)
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
         self._check(_lib.lib().p252_merkle4_openings_device(self._h, d_leaves.data_ptr(), n_leaves, d_levels.data_ptr() if depth else None,
                                                              d_indices.data_ptr(), k, out.data_ptr(), sib.data_ptr() if depth else None,
                                                              pos.data_ptr() if depth else None, bad.data_ptr(), self._stream()))

@@ -86,7 +86,11 @@ def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
         assert k in d, k
     assert "BASELINE configs[1]" in d["config"]["workload"] and d["self_consistency_ok"] is True
     sec = d["secondary"]
-    assert sorted(sec) == ["encrypt", "forest", "openings", "sponge42", "tree"]
+    assert sorted(sec) == ["encrypt", "extract", "forest", "openings", "sponge42", "tree"]
+    x = sec.pop("extract")  # the HBM-bound workload: openings extracted from a stored tree (data movement), the contract's "hbm" shape
+    assert x["roofline"]["bound"] == "hbm" and x["roofline"]["kernel"] == "k_merkle4_openings" and x["unit"] == "opening levels/s"
+    assert x["roofline"]["frac"] == pytest.approx(x["roofline"]["achieved"] / 8000.0) and 0 < x["roofline"]["frac"] < 1
+    assert x["units_per_gpu_per_step"] == (1 << 14) * 9 and x["self_consistency_ok"] is True and x["parity_sample_ok"] is True  # 2^18-leaf tree: depth 9
     f = sec["forest"]  # 2^18 leaves as 64 trees of 4^6 leaves: one launch per level across all trees
     assert "forest of 64 independent arity-4 Merkle trees of 4^6 leaves" in f["workload"] and f["units_per_gpu_per_step"] == 64 * 1365
     assert f["self_consistency_ok"] is True and f["parity_sample_ok"] is True and f["roofline"]["kernel"] == "k_merkle4"
@@ -106,7 +110,7 @@ def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
         assert w["ms_per_step_rank_min"] == w["ms_per_step_rank_max"] == w["ms_per_step_per_rank"][0] <= w["ms_per_step"]
     assert t["roofline"]["kernel"] == "k_merkle4" and s["roofline"]["kernel"] == "k_sponge_lines"
     cb = d["cpu_baseline"]
-    assert cb["parity_samples"] == {"merkle4_digests": True, "tree": True, "forest": True, "sponge42": True, "openings": True, "encrypt": True} and cb["parity_sample_ok"] is True
+    assert cb["parity_samples"] == {"merkle4_digests": True, "tree": True, "forest": True, "sponge42": True, "openings": True, "encrypt": True, "extract": True} and cb["parity_sample_ok"] is True
     # `cores` = the CPUs the box grants (quota / affinity), `threads` = what the fastest run started; the reference's cargo bench is
     # probed at run time (no Rust toolchain on these boxes: reported unavailable with what was missing, never assumed)
     assert cb["threads"] >= 1 and 1 <= cb["cores"] <= cb["cpus_visible"] and "cpu_quota" in cb
@@ -127,7 +131,7 @@ def test_bench_cpu_baseline_leg_checks_gpu_sample(gpu_ctx):
     assert d["self_consistency_ok"] is True
 
 
-@pytest.mark.parametrize("workload,log2n,kernel", [("sponge42", "14", "k_sponge_lines"), ("openings", "14", "k_merkle4_path_lines"), ("tree", "14", "k_merkle4"), ("forest", "16", "k_merkle4"),
+@pytest.mark.parametrize("workload,log2n,kernel", [("sponge42", "14", "k_sponge_lines"), ("openings", "14", "k_merkle4_path_lines"), ("tree", "14", "k_merkle4"), ("forest", "16", "k_merkle4"), ("extract", "12", "k_merkle4_openings"),
                                                    ("encrypt", "14", "k_crypt"),
                                                    # batches of <= 8,192 items run (and are priced as) the lane-group kernels
                                                    ("sponge42", "12", "k_sponge_coop"), ("openings", "11", "k_merkle4_path_coop"),

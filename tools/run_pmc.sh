@@ -51,6 +51,7 @@ case $WL in  # dominant kernel, permutations per launch, algorithmic bytes per p
     sponge42) K=k_sponge; U=$((12 * U20)); B=125.3333 ;;
     openings) K=k_merkle4_path; U=$((12 * U20)); B=102.3333 ;;  # (32 leaf + 12 x 96 siblings + 12 position bytes + 32 root) / 12
     encrypt) K=k_crypt; U=$((2 * U20)); B=128 ;;
+    extract) K=k_merkle4_openings; U=$((12 * U20)); B=198.6667 ;;  # per (opening, level): 96 read + 96 written + 1 position byte, + (64 + 4) / 12 for the leaf and the index
     tree) K=k_merkle4; U=5592405; B=96.0000057; PS=--per-step; NAME=tree ;;
     *) K=k_merkle4; U=$U20; B=96 ;;
 esac
