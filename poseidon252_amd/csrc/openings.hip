@@ -8,7 +8,7 @@
 //   * the reads are gathers by nature (k random paths): one 128-byte line per record at the leaf levels, cache hits higher up;
 //   * piece 0 of a record also stores the position byte; pieces 0 and 1 of level 0 copy the two halves of the leaf.
 // (A first version with one lane per record — six loads and six stores at a 96-byte lane stride — moved 3.19 TB/s algorithmic on
-// random positions, 0.60 of a device-to-device copy: profiles/r04_openings_extract.txt has both.)
+// random positions, 0.70 of a device-to-device copy counting fetched lines: profiles/r04_openings_extract.txt has the steps.)
 // Algorithmic bytes per (opening, level): 96 read + 96 written + 1 position byte (+ 64 per opening for the leaf).
 #include <hip/hip_runtime.h>
 
@@ -18,29 +18,43 @@ namespace p252 {
 
 namespace {
 
+// a value select, not a pointer select: `cond ? array[i] : zero` makes the compiler park `zero` in SCRATCH and load through a selected
+// pointer — 16 bytes of scratch written per lane, 1.2 GB per 2^20 openings of depth 12, which the first counter pass showed as
+// HBM write traffic 1.83 x the algorithmic bytes (profiles/r04_pmc_k_merkle4_openings.txt)
+__device__ __forceinline__ uint4 load_or_zero(const uint4* __restrict__ base, size_t word, bool ok) {
+    uint4 v = base[ok ? word : 0];  // (word 0 always exists: the tree has at least one leaf)
+    v.x = ok ? v.x : 0u;
+    v.y = ok ? v.y : 0u;
+    v.z = ok ? v.z : 0u;
+    v.w = ok ? v.w : 0u;
+    return v;
+}
+
+// IDX = uint32_t whenever the launch has fewer than 2^32 lanes (6 k depth < 2^32: every realistic batch) — the lane's record and
+// level then come from 32-bit divisions; size_t otherwise
+template <class IDX>
 __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restrict__ leaves, size_t n_leaves, const uint4* __restrict__ levels,
                                                           const uint32_t* __restrict__ index, size_t k, unsigned depth,
                                                           uint4* __restrict__ leaves_out, uint4* __restrict__ siblings,
                                                           uint8_t* __restrict__ positions, unsigned* __restrict__ n_bad) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // = the index of the 16-byte word of `siblings` this lane stores
-    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const IDX t = (IDX)blockIdx.x * 256 + threadIdx.x;  // = the index of the 16-byte word of `siblings` this lane stores
     if (depth == 0) {  // a single-leaf tree has no levels: two lanes per opening copy the leaf
         if (t >= 2 * k) return;
         const size_t i = t >> 1, leaf = index[i];
         const bool bad = leaf >= n_leaves;
-        leaves_out[t] = bad ? zero : leaves[2 * leaf + (t & 1)];
+        leaves_out[t] = load_or_zero(leaves, 2 * leaf + (t & 1), !bad);
         if (bad && n_bad && !(t & 1)) atomicAdd(n_bad, 1u);
         return;
     }
-    if (t >= k * depth * 6) return;
-    const size_t rec = t / 6;
+    if (t >= (IDX)(k * depth * 6)) return;
+    const IDX rec = t / 6;
     const unsigned piece = (unsigned)(t - rec * 6), sib = piece >> 1, half = piece & 1u;
-    const size_t i = rec / depth;
+    const IDX i = rec / (IDX)depth;
     const unsigned l = (unsigned)(rec - i * depth);
     const size_t leaf = index[i];
     const bool bad = leaf >= n_leaves;
     if (l == 0 && piece < 2) {
-        leaves_out[2 * i + piece] = bad ? zero : leaves[2 * leaf + piece];
+        leaves_out[2 * (size_t)i + piece] = load_or_zero(leaves, 2 * leaf + piece, !bad);
         if (bad && n_bad && piece == 0) atomicAdd(n_bad, 1u);
     }
     // the array of level l (level 0 = the leaves) and its length: n_0 = n_leaves, n_{l+1} = ceil(n_l / 4)
@@ -53,7 +67,7 @@ __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restric
     const size_t node = leaf >> (2 * l);
     const unsigned p = (unsigned)(node & 3u);
     const size_t j = node - p + sib + (sib >= p ? 1u : 0u);  // the group's nodes in order, the path's own node left out
-    siblings[t] = (!bad && j < cnt) ? nodes[2 * j + half] : zero;  // a ragged level's missing siblings are the zero scalar (hash.rs:22-26)
+    siblings[t] = load_or_zero(nodes, 2 * j + half, !bad && j < cnt);  // a ragged level's missing siblings are the zero scalar (hash.rs:22-26)
     if (piece == 0) positions[rec] = bad ? (uint8_t)0 : (uint8_t)p;
 }
 
@@ -63,9 +77,15 @@ hipError_t launch_merkle4_openings(const void* leaves, size_t n_leaves, const vo
                                    void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st) {
     if (k == 0) return hipSuccess;
     const size_t lanes = depth ? k * depth * 6 : 2 * k;
-    hipLaunchKernelGGL(k_merkle4_openings, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
-                       static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
-                       static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad));
+    const dim3 grid((unsigned)((lanes + 255) / 256));
+    if (lanes + 256 <= 0xffffffffull)
+        hipLaunchKernelGGL(k_merkle4_openings<uint32_t>, grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
+                           static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
+                           static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad));
+    else
+        hipLaunchKernelGGL(k_merkle4_openings<size_t>, grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
+                           static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
+                           static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad));
     return hipGetLastError();
 }
 
