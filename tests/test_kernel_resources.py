@@ -45,6 +45,25 @@ def test_no_scratch_and_register_budget(isa):
             assert o >= 3 and v <= 168, "%s: %d VGPRs, %d waves/SIMD" % (n, v, o)
 
 
+def test_data_movement_kernels_use_no_scratch(tmp_path):
+    """csrc/openings.hip (the HBM-bound extraction of openings): round 4's first counter pass showed HBM writes 1.83 x the algorithmic
+    bytes — `cond ? array[i] : zero` had been compiled into a pointer select with the zero parked in SCRATCH (16 bytes stored per
+    lane).  A data-movement kernel must not touch private memory at all, and must stay far below the register budget of full
+    occupancy (8 waves per SIMD: 64 VGPRs)."""
+    from poseidon252_amd import build as b
+    out = tmp_path / "openings.s"
+    cmd = [b._hipcc()] + [f for f in b.HIPCC_FLAGS if f != "-fPIC"] + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                                                                      "-o", str(out), os.path.join(CSRC, "openings.hip")]
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", proc.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", proc.stderr)]
+    vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", proc.stderr)]
+    assert len(names) == 2 and len(scratch) == 2 and len(vgprs) == 2, proc.stderr[-1500:]  # the uint32 and the size_t instantiation
+    assert scratch == [0, 0] and max(vgprs) <= 32, (names, scratch, vgprs)
+    assert "scratch_" not in open(out).read()
+
+
 def test_code_size_fits_instruction_cache_phases(isa):
     text, _ = isa
     lens = [int(x) for x in re.findall(r"; codeLenInByte = (\d+)", text)]
