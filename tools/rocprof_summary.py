@@ -5,6 +5,11 @@ import sqlite3
 import sys
 
 
+def short_name(name, width):
+    """kernel name without its argument list; '(anonymous namespace)::' is part of the NAME, not the start of the arguments"""
+    return name.replace("(anonymous namespace)::", "").split("(")[0][-width:]
+
+
 def main(path, title="", warm=10):
     db = sqlite3.connect(path)
     cur = db.cursor()
@@ -15,7 +20,7 @@ def main(path, title="", warm=10):
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc"))
     tot = sum(r[2] for r in rows) or 1
     for name, calls, total, avg, mn, mx in rows:
-        short = name.split("(")[0][-58:]
+        short = short_name(name, 58)
         print("%-60s %8d %14.1f %12.1f %12.1f %12.1f %6.2f%%" % (short, calls, total / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * total / tot))
     print()
     print("# timed launches only: grid == the kernel's largest grid (self-check launches of other sizes left out) and the")
@@ -26,7 +31,7 @@ def main(path, title="", warm=10):
         durs = [r[0] for r in cur.execute("select duration from kernels where name = ? and grid_x = ? order by start", (name, gmax))]
         if len(durs) > warm + 1:
             rest, head = durs[warm:], durs[:warm]
-            print("%-60s %8d %12.1f %12.1f %12.1f %14.1f" % (name.split("(")[0][-58:], len(rest), sum(rest) / len(rest) / 1e3, min(rest) / 1e3,
+            print("%-60s %8d %12.1f %12.1f %12.1f %14.1f" % (short_name(name, 58), len(rest), sum(rest) / len(rest) / 1e3, min(rest) / 1e3,
                                                              max(rest) / 1e3, sum(head) / len(head) / 1e3))
     print()
     print("# the library's kernels per launch size (one default bench.py run launches several: configs[1]'s 2^20 digests, the tree's")
@@ -35,7 +40,7 @@ def main(path, title="", warm=10):
     for name, grid in list(cur.execute("select name, grid_x from kernels where name like '%p252::%' group by name, grid_x order by name, grid_x desc")):
         durs = [r[0] for r in cur.execute("select duration from kernels where name = ? and grid_x = ? order by start", (name, grid))]
         rest = durs[warm:] if len(durs) > warm + 1 else []
-        print("%-44s %10d %7d %12.1f %12.1f %12s %12s" % (name.split("(")[0][-42:], grid, len(durs), sum(durs) / len(durs) / 1e3, min(durs) / 1e3,
+        print("%-44s %10d %7d %12.1f %12.1f %12s %12s" % (short_name(name, 42), grid, len(durs), sum(durs) / len(durs) / 1e3, min(durs) / 1e3,
                                                          len(rest) if rest else "-", ("%.1f" % (sum(rest) / len(rest) / 1e3)) if rest else "-"))
     print()
     print("# per-kernel launch geometry / registers (first dispatch)")
@@ -47,7 +52,7 @@ def main(path, title="", warm=10):
             print()
             print("# PMC counters (avg per dispatch, sum, dispatches)")
             for name, cname, avg, sm, n in rows:
-                print("%-40s %-28s avg=%.4g sum=%.4g n=%d" % (name.split("(")[0][-38:], cname, avg, sm, n))
+                print("%-40s %-28s avg=%.4g sum=%.4g n=%d" % (short_name(name, 38), cname, avg, sm, n))
     except sqlite3.Error:
         pass
 
