@@ -979,6 +979,9 @@ def main():
                 print("PARITY FAILURE: GPU output differs from the oracle: %s" % line["cpu_baseline"]["parity_samples"], file=sys.stderr)
                 sys.exit(3)
         print(json.dumps(line))
+    if E._comm is not None:  # the library's communicator goes first, while every rank is still here
+        torch.cuda.synchronize()
+        E._comm.destroy()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
