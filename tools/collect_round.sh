@@ -21,9 +21,12 @@ bash tools/run_pmc.sh sponge42 valu fetch write >> "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh tree fetch write >> "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh openings valu fetch write >> "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh encrypt valu fetch write >> "$O/run_pmc.log" 2>&1
+bash tools/run_pmc.sh extract fetch write >> "$O/run_pmc.log" 2>&1   # the HBM-bound extraction of openings (csrc/openings.hip)
 LOG2N=12 bash tools/run_pmc.sh merkle4_digests valu >> "$O/run_pmc.log" 2>&1
 cp "$ROOT"/gpurun_out/summaries/* "$O/" 2>/dev/null
-for wl in tree sponge42 openings encrypt; do python bench.py --workload $wl --no-cpu-baseline > "$O/bench_$wl.json" 2>/dev/null; done
+for wl in tree forest sponge42 openings encrypt extract; do python bench.py --workload $wl --no-cpu-baseline > "$O/bench_$wl.json" 2>/dev/null; done
+python bench_tools/forest_bench.py --check 2>&1 | grep -v amdgpu.ids > "$O/forest.txt"
+python bench_tools/openings_extract_bench.py 2>&1 | grep -v amdgpu.ids > "$O/openings_extract.txt"
 python bench.py --log2n 12 --no-secondary --no-cpu-baseline > "$O/bench_small4096.json" 2>/dev/null
 python bench.py --log2n 14 --no-secondary --no-cpu-baseline > "$O/bench_small16384.json" 2>/dev/null
 python bench.py --log2n 24 --no-secondary --no-cpu-baseline > "$O/bench_2pow24_digests.json" 2>/dev/null
