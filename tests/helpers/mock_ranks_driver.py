@@ -1,0 +1,119 @@
+"""Driver of tests/test_comm_mock_ranks.py — runs in a subprocess whose P252_LIB_PATH names the library linked against
+tests/cpp/mock_rccl.cpp (several ranks on ONE device).  Prints one JSON line with what it verified."""
+import json
+import os
+import sys
+import threading
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import oracle
+import poseidon252_amd as P
+from poseidon252_amd import comm as C, multi
+
+assert os.environ.get("P252_LIB_PATH") and os.environ.get("P252_COMM_ALLOW_SHARED_DEVICE") == "1"
+tag = P.merkle4_tag()
+report = {}
+
+
+def leaves_of(world, per, seed):
+    return [oracle.fill_random(seed + r, per) for r in range(world)]
+
+
+def ranks_in_threads(world, per, seed, repeats):
+    """one thread per rank, each with its own context: p252_comm_unique_id on rank 0, the id handed round, p252_comm_create_rank on every
+    rank (collective; broadcasts and validates the constants), then p252_merkle4_tree_sharded_device `repeats` times"""
+    lv = leaves_of(world, per, seed)
+    exp = oracle.merkle4_tree(tag, np.concatenate(lv))[0]
+    box, got, errs = {}, [None] * world, []
+    ready = threading.Barrier(world)
+
+    def exchange_for(rank):
+        def exchange(id_bytes):
+            if rank == 0:
+                box["id"] = id_bytes
+            ready.wait()
+            return box["id"]
+        return exchange
+
+    def run(rank):
+        try:
+            ctx = P.Context(0)
+            c = C.Comm.create_rank(ctx, rank, world, exchange_for(rank))
+            assert c.rank == rank and c.size == world
+            d = torch.from_numpy(lv[rank].view(np.int64).copy()).to("cuda:0")
+            d_root = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+            for _ in range(repeats):
+                d_root.zero_()
+                c.merkle4_tree_sharded_device(tag, d, per, d_root)
+                torch.cuda.synchronize()
+                assert np.array_equal(d_root.cpu().numpy().view(np.uint64), exp), "rank %d: root differs from the oracle's" % rank
+            got[rank] = d_root.cpu().numpy().view(np.uint64).copy()
+            ready.wait()  # every rank still here when the communicators go
+            c.destroy()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append("rank %d: %r" % (rank, e))
+            try:
+                ready.abort()
+            except Exception:
+                pass
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs and not any(t.is_alive() for t in ts), errs
+    assert all(np.array_equal(g, exp) for g in got)
+
+
+for world, per in ((8, 4 ** 5), (2, 4 ** 6), (3, 4 ** 3), (5, 16), (8, 1)):
+    ranks_in_threads(world, per, 0xC10D + world, repeats=3)
+report["one thread per rank (p252_comm_create_rank + p252_merkle4_tree_sharded_device)"] = "worlds 8, 2, 3, 5, 8 x 3 builds: every rank's root == the oracle's tree over the concatenation"
+
+# one process, an array of contexts (p252_comm_create_all; one thread drives every rank inside ncclGroupStart / End)
+for world, per in ((8, 4 ** 5), (4, 4 ** 4), (3, 4 ** 2), (6, 4)):
+    ctxs = [P.Context(0) for _ in range(world)]
+    comms = C.Comm.create_all(ctxs)
+    assert [c.rank for c in comms] == list(range(world)) and all(c.size == world for c in comms)
+    lv = leaves_of(world, per, 0xABC + world)
+    exp = oracle.merkle4_tree(tag, np.concatenate(lv))[0]
+    d = [torch.from_numpy(x.view(np.int64).copy()).to("cuda:0") for x in lv]
+    for _ in range(2):
+        assert np.array_equal(multi.merkle4_tree_multi_device(ctxs, tag, d, per), exp)
+    d_roots = [torch.zeros(4, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+    C.merkle4_tree_multi_device_resident(ctxs, tag, d, per, d_roots)
+    torch.cuda.synchronize()
+    assert all(np.array_equal(r.cpu().numpy().view(np.uint64), exp) for r in d_roots)  # the root is resident on EVERY rank
+    try:  # the contexts in another order are not this clique (rank t must be ctxs[t]) and already belong to a communicator
+        multi.merkle4_tree_multi_device(ctxs[::-1], tag, d, per)
+        raise SystemExit("a permuted context array was accepted")
+    except ValueError:
+        pass
+    for c in comms:
+        c.destroy()
+    for c in ctxs:
+        c.close()
+report["one process, array of contexts (p252_comm_create_all, p252_merkle4_tree_multi_device[_resident])"] = "worlds 8, 4, 3, 6: root == oracle, resident on every rank"
+
+# the multi-device entry point creating its communicator itself, and taking it along when the contexts are destroyed
+ctxs = [P.Context(0) for _ in range(8)]
+lv = leaves_of(8, 4 ** 4, 0x5151)
+d = [torch.from_numpy(x.view(np.int64).copy()).to("cuda:0") for x in lv]
+assert np.array_equal(multi.merkle4_tree_multi_device(ctxs, tag, d, 4 ** 4), oracle.merkle4_tree(tag, np.concatenate(lv))[0])
+try:
+    C.Comm.create_all(ctxs)
+    raise SystemExit("contexts that already belong to the library-made communicator were accepted")
+except ValueError:
+    pass
+for c in ctxs:
+    c.close()
+ctxs = [P.Context(0) for _ in range(8)]  # and again with fresh contexts: nothing of the first clique is left behind
+assert np.array_equal(multi.merkle4_tree_multi_device(ctxs, tag, d, 4 ** 4), oracle.merkle4_tree(tag, np.concatenate(lv))[0])
+for c in ctxs:
+    c.close()
+report["communicator created on first use by p252_merkle4_tree_multi_device, destroyed with its contexts"] = "ok, twice"
+print(json.dumps(report))
