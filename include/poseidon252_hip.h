@@ -56,7 +56,8 @@ extern "C" {
  *   5  + p252_abi_version, p252_merkle4_update_checked_device, p252_clock_probe_device, p252_staging_lanes; out-of-range
  *      indices of p252_merkle4_update_device are skipped (were undefined behaviour)
  *   6  + the RCCL communicator (p252_comm_*), p252_merkle4_tree_sharded_device, p252_merkle4_tree_multi_device_resident,
- *      p252_merkle4_forest[_device], p252_merkle2_forest_device, p252_merkle4_openings_device, p252_merkle4_depth, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
+ *      p252_merkle4_forest[_device], p252_merkle2_forest_device, p252_merkle{4,2}_openings_device, p252_merkle{4,2}_depth,
+ *      p252_merkle2_path_batch_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
  *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on) */
 #define P252_ABI_VERSION 6
 
@@ -219,6 +220,14 @@ int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
 size_t p252_merkle4_depth(size_t n_leaves);
 int p252_merkle4_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
                                  void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream);
+/* The arity-2 twins (Domain::Merkle2 trees as p252_merkle2_tree_device builds them; pass the Merkle2 tag): ONE sibling per level —
+ * d_siblings[k][depth], d_positions[k][depth] in 0..1 (1 = the path's node is the right child), depth = p252_merkle2_depth(n_leaves);
+ * p252_merkle2_path_batch_device re-hashes n such openings (depth sequential Hash::digest(Domain::Merkle2, [left, right]) per lane). */
+size_t p252_merkle2_depth(size_t n_leaves);
+int p252_merkle2_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
+                                 void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream);
+int p252_merkle2_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                   const void* d_positions, size_t depth, void* d_roots, size_t n, void* hip_stream);
 
 /* A FOREST of n_trees independent complete arity-4 trees of leaves_per_tree = 4^k leaves each (the downstream poseidon-merkle
  * shape, AGENTS.md:62-66: many small trees), tree-major in d_leaves.  Level l of all trees is one array of

@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "p252_abi_version", "p252_merkle4_update_checked_device", "p252_clock_probe_device", "p252_staging_lanes",
     "p252_comm_unique_id", "p252_comm_create_rank", "p252_comm_create_all", "p252_comm_destroy", "p252_comm_rank", "p252_comm_size",
     "p252_merkle4_tree_sharded_device", "p252_merkle4_tree_multi_device_resident", "p252_merkle4_forest_device", "p252_merkle2_forest_device", "p252_merkle4_forest", "p252_merkle4_openings_device", "p252_merkle4_depth",
+    "p252_merkle2_openings_device", "p252_merkle2_depth", "p252_merkle2_path_batch_device",
 )
 ABI_VERSION = 6  # include/poseidon252_hip.h P252_ABI_VERSION this binding was written against
 
@@ -200,6 +201,10 @@ def lib():
     L.p252_merkle4_openings_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]
     L.p252_merkle4_depth.argtypes = [_sz]
     L.p252_merkle4_depth.restype = _sz
+    L.p252_merkle2_openings_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]
+    L.p252_merkle2_depth.argtypes = [_sz]
+    L.p252_merkle2_depth.restype = _sz
+    L.p252_merkle2_path_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
     L.p252_abi_version.restype = ctypes.c_int
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)

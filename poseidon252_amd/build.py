@@ -15,7 +15,7 @@ HIPCC_FLAGS = [
     # silently turns them into scratch-indexed loops
     "-mllvm", "-pragma-unroll-threshold=1000000",
 ]
-SOURCES = ["kernels.hip", "openings.hip", "api.cpp", "comm.cpp"]
+SOURCES = ["kernels.hip", "openings.hip", "merkle2.hip", "api.cpp", "comm.cpp"]
 # comm.cpp: the RCCL communicator of the multi-GPU entry points (ncclBroadcast of the constants, ncclAllGather of subtree roots)
 LINK_FLAGS = ["-L/opt/rocm/lib", "-lrccl"]
 HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp", "ctx.hpp", "openings.h",

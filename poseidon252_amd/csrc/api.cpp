@@ -874,6 +874,26 @@ int p252_merkle4_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const v
     return P252_OK;
 }
 
+// arity-2 twin of p252_merkle4_path_batch_device (Domain::Merkle2 nodes; pass the Merkle2 tag): siblings[n][depth], positions 0..1
+int p252_merkle2_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                   const void* d_positions, size_t depth, void* d_roots, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    if (!tag || !d_leaves || !d_roots || (depth && (!d_siblings || !d_positions)))
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle2_path: NULL buffer");
+    if (depth > 0xffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle2_path: depth too large");
+    if (misaligned(d_leaves) || misaligned(d_roots) || (depth && misaligned(d_siblings))) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_merkle2_path(ctx->d_tab, tag_arg(tag), d_leaves, d_siblings, d_positions, (unsigned)depth, d_roots, n, (hipStream_t)hip_stream));
+    return P252_OK;
+}
+
+size_t p252_merkle2_depth(size_t n_leaves) {
+    size_t d = 0;
+    for (size_t c = n_leaves; c > 1; c = (c + 1) / 2) ++d;
+    return d;
+}
+
 // depth of the arity-4 tree over n_leaves = number of levels above the leaves (a 4^k-leaf tree: k; a single leaf: 0)
 size_t p252_merkle4_depth(size_t n_leaves) {
     size_t d = 0;
@@ -884,12 +904,12 @@ size_t p252_merkle4_depth(size_t n_leaves) {
 // Openings of a STORED tree, extracted on the device (openings.hip: pure data movement): for each of the k leaf positions the
 // leaf, the three siblings per level and the position bytes, in exactly the layout p252_merkle4_path_batch_device takes — build
 // (all levels) -> extract -> verify never leaves the GPU.
-int p252_merkle4_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
-                                 void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream) {
+static int openings_device(p252_ctx* ctx, unsigned arity, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
+                           void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (k == 0) return P252_OK;
     if (n_leaves == 0 || n_leaves > 0xffffffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: n_leaves must be in 1 .. 2^32 - 1 (positions are uint32)");
-    const size_t depth = p252_merkle4_depth(n_leaves);
+    const size_t depth = arity == 4 ? p252_merkle4_depth(n_leaves) : p252_merkle2_depth(n_leaves);
     if (!d_leaves || !d_indices || !d_leaves_out || (depth && (!d_levels || !d_siblings || !d_positions)))
         return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: NULL buffer");
     if (misaligned(d_leaves) || misaligned(d_levels) || misaligned(d_leaves_out) || misaligned(d_siblings)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
@@ -898,8 +918,19 @@ int p252_merkle4_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_l
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (d_n_bad) HIP_TRY(ctx, hipMemsetAsync(d_n_bad, 0, 4, st));
-    HIP_TRY(ctx, launch_merkle4_openings(d_leaves, n_leaves, d_levels, d_indices, k, (unsigned)depth, d_leaves_out, d_siblings, d_positions, d_n_bad, st));
+    HIP_TRY(ctx, (arity == 4 ? launch_merkle4_openings : launch_merkle2_openings)(d_leaves, n_leaves, d_levels, d_indices, k, (unsigned)depth, d_leaves_out, d_siblings,
+                                                                                       d_positions, d_n_bad, st));
     return P252_OK;
+}
+
+int p252_merkle4_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
+                                 void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream) {
+    return openings_device(ctx, 4, d_leaves, n_leaves, d_levels, d_indices, k, d_leaves_out, d_siblings, d_positions, d_n_bad, hip_stream);
+}
+
+int p252_merkle2_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_leaves, const void* d_levels, const void* d_indices, size_t k,
+                                 void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream) {
+    return openings_device(ctx, 2, d_leaves, n_leaves, d_levels, d_indices, k, d_leaves_out, d_siblings, d_positions, d_n_bad, hip_stream);
 }
 
 int p252_merkle4_path_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* leaves, const uint64_t* siblings,

@@ -1,0 +1,70 @@
+// merkle2.hip — branch re-hash of arity-2 Merkle openings ("batched path recomputation ... and Domain::Merkle2").
+// node = Hash::digest(Domain::Merkle2, [left, right]) = perm([tag, left, right, 0, 0])[1] (hash.rs:27-31 with io-pattern
+// [Absorb(2), Squeeze(1)]); a lane walks its depth levels sequentially, the sibling of each level on the side its position bit says.
+// The permutation is the library's (hades29.hpp, the digest specialisation of k_merkle4: tag S-box hoisted to the host, only the
+// squeezed row of the last layer); this file only adds the arity-2 walk.  Its own translation unit: kernels.hip — whose source digest
+// the committed counter passes and ISA counts are keyed to — is untouched.
+#include <hip/hip_runtime.h>
+
+#include "hades29.hpp"
+#include "kernels.h"
+#include "openings.h"
+
+namespace p252 {
+
+namespace {
+
+struct alignas(16) Rec {
+    uint32_t w[8];
+};
+
+__device__ __forceinline__ E29 load_rec(const Rec* __restrict__ p) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(p);
+    const uint4 hi = *(reinterpret_cast<const uint4*>(p) + 1);
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return from_mont4(w);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(P252_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_merkle2_path(const int32_t* __restrict__ tab, TagArg tag, const Rec* __restrict__ leaves, const Rec* __restrict__ siblings,
+               const uint8_t* __restrict__ positions, unsigned depth, Rec* __restrict__ roots, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    E29 cur = load_rec(leaves + idx);
+    const Rec* sib = siblings + idx * depth;
+    const uint8_t* pos = positions + idx * depth;
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; ++l) {
+        const bool right = (pos[l] & 1u) != 0;  // the path's node is the RIGHT child
+        const E29 other = load_rec(sib + l);
+        E29 s[WIDTH];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            s[0].d[k] = tag.x0[k];  // lane 0 enters after its first S-box (hades_permute PRE0)
+            s[1].d[k] = right ? other.d[k] : cur.d[k];
+            s[2].d[k] = right ? cur.d[k] : other.d[k];
+        }
+        s[3] = e29_zero();
+        s[4] = e29_zero();
+        hades_permute<0x02u, true>(s, tab);
+        cur = s[1];
+    }
+    uint32_t w[8];
+    to_mont4(cur, w);
+    Rec* out = roots + idx;
+    *reinterpret_cast<uint4*>(out) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(reinterpret_cast<uint4*>(out) + 1) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+hipError_t launch_merkle2_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings, const void* positions, unsigned depth,
+                               void* roots, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merkle2_path, dim3((unsigned)((n + P252_BLOCK - 1) / P252_BLOCK)), dim3(P252_BLOCK), 0, st, tab, tag,
+                       static_cast<const Rec*>(leaves), static_cast<const Rec*>(siblings), static_cast<const uint8_t*>(positions), depth,
+                       static_cast<Rec*>(roots), n);
+    return hipGetLastError();
+}
+
+}  // namespace p252

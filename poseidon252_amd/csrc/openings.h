@@ -15,4 +15,13 @@ namespace p252 {
 hipError_t launch_merkle4_openings(const void* leaves, size_t n_leaves, const void* levels, const void* index, size_t k, unsigned depth,
                                    void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st);
 
+// the same for an arity-2 tree (Domain::Merkle2): siblings[k][depth][1], positions in 0..1
+hipError_t launch_merkle2_openings(const void* leaves, size_t n_leaves, const void* levels, const void* index, size_t k, unsigned depth,
+                                   void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st);
+
+// merkle2.hip: re-hash of n arity-2 openings (depth sequential Merkle2 digests per lane): siblings[n][depth], positions[n][depth] in 0..1
+struct TagArg;
+hipError_t launch_merkle2_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings, const void* positions, unsigned depth,
+                               void* roots, size_t n, hipStream_t st);
+
 }  // namespace p252

@@ -32,7 +32,8 @@ __device__ __forceinline__ uint4 load_or_zero(const uint4* __restrict__ base, si
 
 // IDX = uint32_t whenever the launch has fewer than 2^32 lanes (6 k depth < 2^32: every realistic batch) — the lane's record and
 // level then come from 32-bit divisions; size_t otherwise
-template <class IDX>
+// ARITY 4: three siblings per level (six 16-byte pieces per record); ARITY 2 (Domain::Merkle2 trees): one sibling (two pieces)
+template <class IDX, unsigned ARITY>
 __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restrict__ leaves, size_t n_leaves, const uint4* __restrict__ levels,
                                                           const uint32_t* __restrict__ index, size_t k, unsigned depth,
                                                           uint4* __restrict__ leaves_out, uint4* __restrict__ siblings,
@@ -46,9 +47,10 @@ __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restric
         if (bad && n_bad && !(t & 1)) atomicAdd(n_bad, 1u);
         return;
     }
-    if (t >= (IDX)(k * depth * 6)) return;
-    const IDX rec = t / 6;
-    const unsigned piece = (unsigned)(t - rec * 6), sib = piece >> 1, half = piece & 1u;
+    constexpr unsigned PIECES = 2 * (ARITY - 1), SHIFT = ARITY == 4 ? 2 : 1;
+    if (t >= (IDX)(k * depth * PIECES)) return;
+    const IDX rec = t / PIECES;
+    const unsigned piece = (unsigned)(t - rec * PIECES), sib = piece >> 1, half = piece & 1u;
     const IDX i = rec / (IDX)depth;
     const unsigned l = (unsigned)(rec - i * depth);
     const size_t leaf = index[i];
@@ -62,10 +64,10 @@ __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restric
     size_t cnt = n_leaves;
     for (unsigned j = 0; j < l; ++j) {  // (at most `depth` trips of two integer operations: nothing beside the line fetch)
         nodes = j == 0 ? levels : nodes + 2 * cnt;
-        cnt = (cnt + 3) >> 2;
+        cnt = (cnt + ARITY - 1) >> SHIFT;
     }
-    const size_t node = leaf >> (2 * l);
-    const unsigned p = (unsigned)(node & 3u);
+    const size_t node = leaf >> (SHIFT * l);
+    const unsigned p = (unsigned)(node & (ARITY - 1));
     const size_t j = node - p + sib + (sib >= p ? 1u : 0u);  // the group's nodes in order, the path's own node left out
     siblings[t] = load_or_zero(nodes, 2 * j + half, !bad && j < cnt);  // a ragged level's missing siblings are the zero scalar (hash.rs:22-26)
     if (piece == 0) positions[rec] = bad ? (uint8_t)0 : (uint8_t)p;
@@ -73,20 +75,30 @@ __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restric
 
 }  // namespace
 
-hipError_t launch_merkle4_openings(const void* leaves, size_t n_leaves, const void* levels, const void* index, size_t k, unsigned depth,
-                                   void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st) {
+template <unsigned ARITY>
+static hipError_t launch_openings(const void* leaves, size_t n_leaves, const void* levels, const void* index, size_t k, unsigned depth,
+                                  void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st) {
     if (k == 0) return hipSuccess;
-    const size_t lanes = depth ? k * depth * 6 : 2 * k;
+    const size_t lanes = depth ? k * depth * 2 * (ARITY - 1) : 2 * k;
     const dim3 grid((unsigned)((lanes + 255) / 256));
     if (lanes + 256 <= 0xffffffffull)
-        hipLaunchKernelGGL(k_merkle4_openings<uint32_t>, grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
+        hipLaunchKernelGGL((k_merkle4_openings<uint32_t, ARITY>), grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
                            static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
                            static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad));
     else
-        hipLaunchKernelGGL(k_merkle4_openings<size_t>, grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
+        hipLaunchKernelGGL((k_merkle4_openings<size_t, ARITY>), grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
                            static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
                            static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad));
     return hipGetLastError();
+}
+
+hipError_t launch_merkle4_openings(const void* leaves, size_t n_leaves, const void* levels, const void* index, size_t k, unsigned depth,
+                                   void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st) {
+    return launch_openings<4>(leaves, n_leaves, levels, index, k, depth, leaves_out, siblings, positions, n_bad, st);
+}
+hipError_t launch_merkle2_openings(const void* leaves, size_t n_leaves, const void* levels, const void* index, size_t k, unsigned depth,
+                                   void* leaves_out, void* siblings, void* positions, void* n_bad, hipStream_t st) {
+    return launch_openings<2>(leaves, n_leaves, levels, index, k, depth, leaves_out, siblings, positions, n_bad, st);
 }
 
 }  // namespace p252

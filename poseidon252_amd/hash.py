@@ -302,30 +302,41 @@ class Context:
                                                         roots.ctypes.data_as(_u64p), n))
         return roots
 
-    def merkle4_openings_device(self, d_leaves, n_leaves, d_levels, d_indices, k, check=False, out=None):
+    def merkle4_openings_device(self, d_leaves, n_leaves, d_levels, d_indices, k, check=False, out=None, arity=4):
         """openings of a stored tree, extracted on the device (p252_merkle4_openings_device): d_indices = k leaf positions (int32 /
         uint32 torch tensor).  Returns (d_leaves_out (k,4), d_siblings (k,depth,3,4), d_positions (k,depth) uint8, depth) — what
         merkle4_path_batch_device takes.  check=True: raises if a position lies outside the tree (they yield zero openings);
-        out = (d_leaves_out, d_siblings, d_positions, d_n_bad) to write into caller-owned tensors (no allocation per call)."""
+        out = (d_leaves_out, d_siblings, d_positions, d_n_bad) to write into caller-owned tensors (no allocation per call).
+        arity=2: a Merkle2 tree (p252_merkle2_openings_device): one sibling per level, d_siblings (k,depth,1,4)."""
         import torch
-        assert d_leaves.is_cuda and d_indices.is_cuda and d_indices.element_size() == 4 and d_indices.is_contiguous()
-        depth = int(_lib.lib().p252_merkle4_depth(n_leaves))
-        assert self._nbytes(d_leaves) >= n_leaves * 32 and (depth == 0 or self._nbytes(d_levels) >= _lib.lib().p252_merkle4_levels_len(n_leaves) * 32)
+        assert d_leaves.is_cuda and d_indices.is_cuda and d_indices.element_size() == 4 and d_indices.is_contiguous() and arity in (2, 4)
+        L = _lib.lib()
+        depth = int((L.p252_merkle4_depth if arity == 4 else L.p252_merkle2_depth)(n_leaves))
+        ll = (L.p252_merkle4_levels_len if arity == 4 else L.p252_merkle2_levels_len)(n_leaves)
+        assert self._nbytes(d_leaves) >= n_leaves * 32 and (depth == 0 or self._nbytes(d_levels) >= ll * 32)
         dev = d_leaves.device
         if out is not None:
             out, sib, pos, bad = out
-            assert self._nbytes(out) >= k * 32 and self._nbytes(sib) >= k * depth * 96 and self._nbytes(pos) >= k * depth and self._nbytes(bad) >= 4
+            assert self._nbytes(out) >= k * 32 and self._nbytes(sib) >= k * depth * 32 * (arity - 1) and self._nbytes(pos) >= k * depth and self._nbytes(bad) >= 4
         else:
             out = torch.empty((k, 4), dtype=torch.int64, device=dev)
-            sib = torch.empty((k, depth, 3, 4), dtype=torch.int64, device=dev)
+            sib = torch.empty((k, depth, arity - 1, 4), dtype=torch.int64, device=dev)
             pos = torch.empty((k, depth), dtype=torch.uint8, device=dev)
             bad = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._check(_lib.lib().p252_merkle4_openings_device(self._h, d_leaves.data_ptr(), n_leaves, d_levels.data_ptr() if depth else None,
-                                                             d_indices.data_ptr(), k, out.data_ptr(), sib.data_ptr() if depth else None,
-                                                             pos.data_ptr() if depth else None, bad.data_ptr(), self._stream()))
+        fn = L.p252_merkle4_openings_device if arity == 4 else L.p252_merkle2_openings_device
+        self._check(fn(self._h, d_leaves.data_ptr(), n_leaves, d_levels.data_ptr() if depth else None, d_indices.data_ptr(), k, out.data_ptr(),
+                       sib.data_ptr() if depth else None, pos.data_ptr() if depth else None, bad.data_ptr(), self._stream()))
         if check and int(bad.item()):
             raise ValueError("merkle4_openings: %d position(s) outside the tree" % int(bad.item()))
         return out, sib, pos, depth
+
+    def merkle2_path_batch_device(self, tag, d_leaves, d_siblings, d_positions, depth, d_roots, n):
+        """re-hash of n arity-2 openings (Domain::Merkle2; pass the Merkle2 tag): d_siblings (n,depth[,1],4), d_positions (n,depth) in 0..1"""
+        tag = _as_scalars(tag).reshape(4)
+        assert d_leaves.is_cuda and d_roots.is_cuda and self._nbytes(d_leaves) >= n * 32 and self._nbytes(d_roots) >= n * 32
+        assert depth == 0 or (self._nbytes(d_siblings) >= n * depth * 32 and self._nbytes(d_positions) >= n * depth)
+        self._check(_lib.lib().p252_merkle2_path_batch_device(self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), d_siblings.data_ptr() if depth else None,
+                                                               d_positions.data_ptr() if depth else None, depth, d_roots.data_ptr(), n, self._stream()))
 
     def merkle4_path_batch_device(self, tag, d_leaves, d_siblings, d_positions, depth, d_roots, n):
         tag = _as_scalars(tag).reshape(4)

@@ -59,8 +59,8 @@ def test_data_movement_kernels_use_no_scratch(tmp_path):
     names = re.findall(r"Function Name: (\S+)", proc.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", proc.stderr)]
     vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", proc.stderr)]
-    assert len(names) == 2 and len(scratch) == 2 and len(vgprs) == 2, proc.stderr[-1500:]  # the uint32 and the size_t instantiation
-    assert scratch == [0, 0] and max(vgprs) <= 32, (names, scratch, vgprs)
+    assert len(names) == 4 and len(scratch) == 4 and len(vgprs) == 4, proc.stderr[-1500:]  # {uint32, size_t} lane index x {arity 4, arity 2}
+    assert scratch == [0, 0, 0, 0] and max(vgprs) <= 32, (names, scratch, vgprs)
     assert "scratch_" not in open(out).read()
 
 
