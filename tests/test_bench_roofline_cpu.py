@@ -1,0 +1,84 @@
+"""bench.py's roofline arithmetic without a GPU: the top-level scalars of `roofline` are the HARDWARE fraction —
+executed multiply-adds (ISA-derived count from profiles/) x units per launch / launch time / (1024 SIMDs x 2.4 GHz / 4 x 64 lanes) —
+with SURVEY §8d's 256,000-MAC reference-schedule pricing under its own name; the HBM-shaped roofline of the extraction workload;
+counter traffic from the committed passes.  The numbers fed in are round 4's measured launch times, so the expected fractions are
+the ones DESIGN.md quotes."""
+import os
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _w(key, n, units, **kw):
+    W = types.SimpleNamespace(key=key, n=n, perms_per_step=units, **kw)
+    return W
+
+
+CLK = {"shader_ghz": 2.36, "interval_us": 3000.0, "cycles_per_dependent_add": 44.0}
+
+
+def test_digest_roofline_is_the_hardware_fraction():
+    W = _w("merkle4_digests", 1 << 20, 1 << 20)
+    r = bench.roofline_of(W, [2.108, 2.110, 2.106], CLK, dict(CLK, shader_ghz=2.362))
+    assert r["bound"] == "valu-int32-mac" and r["kernel"] == "k_merkle4" and r["unit"] == "TMAC/s"
+    assert r["peak"] == pytest.approx(1024 * 2.4e9 / 4 * 64 / 1e12) == pytest.approx(39.3216)
+    assert r["macs_per_perm_executed"] == 61237 and r["valu_insts_per_perm"] == 76983  # profiles/r03_isa_counts.json (kernels unchanged since)
+    assert r["achieved"] == pytest.approx(61237 * (1 << 20) / 2.108e-3 / 1e12, rel=1e-3)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.77 < r["frac"] < 0.78
+    assert r["clock_ghz_measured"] == pytest.approx(2.361) and r["frac_at_measured_clock"] == pytest.approx(r["frac"] * 2.4 / 2.361)
+    assert r["frac"] < r["frac_valu_issue"] < 1 and r["frac_valu_issue"] == pytest.approx(288104 / 4 / 61237 * r["frac"], rel=1e-6)
+    # the reference schedule's pricing is kept, under its own name, and is NOT the fraction
+    assert r["frac_reference_schedule"] == pytest.approx(r["frac"] * 256000 / 61237) and r["frac_reference_schedule"] > 3
+    assert r["achieved_reference_schedule"] == pytest.approx(256000 * (1 << 20) / (r["launch_ms_mean"] * 1e-3) / 1e12)
+    # counter traffic of the committed pass, per launch, next to the algorithmic bytes
+    assert r["traffic_algorithmic_bytes"] == 160.0 * (1 << 20)
+    assert r["traffic"] == pytest.approx(1.0095 * 160 * (1 << 20), rel=2e-3) and r["traffic_ratio"] == pytest.approx(1.0095, rel=2e-3)
+    assert r["hbm_frac"] < 0.011
+    for k, v in r.items():  # what the driver's record keeps: every headline figure is a top-level scalar
+        if k in ("achieved", "peak", "frac", "frac_at_measured_clock", "frac_valu_issue", "macs_per_perm_executed", "clock_ghz_measured", "traffic",
+                 "traffic_ratio", "frac_reference_schedule", "launch_ms_mean"):
+            assert isinstance(v, (int, float)) and not isinstance(v, bool), k
+
+
+def test_small_batches_are_priced_as_the_lane_group_kernels():
+    r = bench.roofline_of(_w("merkle4_digests", 4096, 4096), [0.115], CLK, CLK)
+    assert r["kernel"] == "k_merkle4_coop<8>" and r["macs_per_perm_executed"] == 8 * r["executed"]["macs_per_perm"] // 8
+    # eight lanes per digest: 32,768 lanes = one wave on half of the SIMDs, each lane issuing 37.8 k multiply-adds in 0.115 ms
+    assert r["valu_issue"]["lanes_per_perm"] == 8 and 0.2 < r["frac"] < 0.35
+    r4 = bench.roofline_of(_w("merkle4_digests", 16384, 16384), [0.128], CLK, CLK)
+    assert r4["kernel"] == "k_merkle4_coop<4>" and r4["valu_issue"]["lanes_per_perm"] == 4
+
+
+def test_tree_and_forest_traffic_come_from_the_tree_passes():
+    units = (4 ** 12 - 1) // 3
+    t = bench.roofline_of(_w("tree", 1 << 24, units), [12.2], CLK, CLK)
+    assert t["kernel"] == "k_merkle4" and t["traffic_ratio"] == pytest.approx(1.714, rel=2e-3)
+    assert t["traffic_detail"]["ratio_level_by_level"] == pytest.approx(1.03, abs=0.01)  # against what a level-by-level build must move
+    bench.BYTES_PER_PERM["forest"] = (4096 * 32 + 32) / 1365.0
+    f = bench.roofline_of(_w("forest", 1 << 24, 4096 * 1365), [11.66], CLK, CLK)
+    assert f["kernel"] == "k_merkle4" and f["frac"] > t["frac"] and f["traffic_ratio"] == pytest.approx(1.713, rel=3e-3)
+
+
+def test_extraction_is_priced_against_the_hbm_roofline():
+    k, depth = 1 << 20, 12
+    W = _w("extract", k, k * depth, bytes_per_unit=96.0 + 96.0 + 1.0 + 68.0 / depth)
+    r = bench.roofline_of(W, [0.616, 0.614], CLK, CLK)
+    assert r["bound"] == "hbm" and r["kernel"] == "k_merkle4_openings" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    alg = k * (depth * 193 + 68)
+    assert r["traffic_algorithmic_bytes"] == pytest.approx(alg) and r["achieved"] == pytest.approx(alg / 0.615e-3 / 1e9, rel=1e-6)
+    assert r["frac"] == pytest.approx(r["achieved"] / 8000.0) and 0.50 < r["frac"] < 0.52
+    # the committed FETCH x 2 + WRITE passes of the final kernel (scratch 0): reads below algorithmic (upper levels hit in cache), writes equal
+    assert r["traffic_source"] == "profiles/r04_pmc_k_merkle4_openings.json" and r["traffic_ratio"] == pytest.approx(0.823, abs=0.005)
+
+
+def test_cpu_baseline_plumbing_probes_at_run_time():
+    rc = bench.reference_cargo_bench()
+    assert set(rc["probe"]) == {"cargo", "rustc", "reference_dir", "crate_registry"} and rc["command"].startswith("cargo bench --features=zk --bench hash")
+    if not rc["available"]:
+        assert rc["why"].startswith("not on this box: ") and all(name in rc["why"] for name, v in rc["probe"].items() if not v)
+    assert 1 <= bench.usable_cpus() <= (os.cpu_count() or 1)
