@@ -32,7 +32,13 @@ against the 100 MHz s_memrealtime) runs on a second stream beside extra untimed 
 each timed region — the clock under this very load — and every roofline fraction is given at the nominal 2.4 GHz
 AND at the measured clock.
 
-Prints ONE JSON line (rank 0) with `roofline` (VALU int32-MAC bound — DESIGN.md §3; HBM figures are
+Prints ONE JSON line (rank 0) of SCALARS ONLY, under 6,000 bytes (the driver keeps an 8 KB tail of stdout; round 4's 26 KB
+line could not be parsed): the contract's keys, `roofline`, `cpu_baseline` and each secondary as a handful of scalars.  The full
+record — nested models (`executed`, `valu_issue`, `clock`, `hbm`, `traffic_detail`), per-rank arrays, sources and notes — is written
+to bench_detail.json next to this file (`detail_file` on the line; --detail-file).  As soon as the primary is measured a minimal
+record of it also goes to stderr ("bench.py primary: {...}").
+
+The line carries `roofline` (VALU int32-MAC bound — DESIGN.md §3; HBM figures are
 included, the path is not HBM- or MFMA-bound) and, at N=1, `cpu_baseline` (the C oracle, kind "port",
 timed on the host cores on a bounded sample).  oracle/ is touched ONLY inside that cpu_baseline leg,
 where it is timed and, as a by-product, checks a sample of the GPU output of every workload just measured; every
@@ -113,6 +119,8 @@ def parse():
     ap.add_argument("--secondary-timeout", type=int, default=240, help="N > 1: seconds a secondary workload may take before the line is printed without it (0 = no watchdog)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where rank 0 writes the full record (nested models, sources, per-rank arrays, notes); the printed line names it")
     return ap.parse_args()
 
 
@@ -803,6 +811,105 @@ def roofline_of(W, launch_ms, clk_before, clk_after, sclk_sysfs=None):
     }
 
 
+# ---- the printed line -------------------------------------------------------------------------------------
+# The driver keeps an 8 KB tail of stdout; round 4's line had grown to 26 KB and could no longer be parsed.  bench.py therefore
+# builds the full record as before (every source, probe, nested model and note: `detail`), writes it to a side file next to
+# bench.py (--detail-file) and PRINTS a line of scalars only, whose length is bounded and asserted.
+LINE_BUDGET_BYTES = 6000
+ROOFLINE_SCALARS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_at_measured_clock", "frac_valu_issue", "macs_per_perm_executed",
+                    "clock_ghz_measured", "launch_ms_mean", "units_per_launch", "traffic", "traffic_ratio", "frac_reference_schedule")
+SECONDARY_SCALARS = ("value", "unit", "units_per_gpu_per_step", "ms_per_step", "steps", "ms_per_step_rank_min", "ms_per_step_rank_max",
+                     "self_consistency_ok", "parity_sample_ok")
+
+
+def _sig(v, digits=7):
+    """floats at `digits` significant digits (a 17-digit repr is 2.5 x the bytes and carries no information here)"""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, v))
+
+
+def _short(text, limit):
+    return text if text is None or len(text) <= limit else text[:limit - 3] + "..."
+
+
+def compact_roofline(r):
+    return {k: _sig(r.get(k)) for k in ROOFLINE_SCALARS}
+
+
+def compact_line(detail, detail_file=None):
+    """the ONE line printed on stdout: the contract's keys, `roofline` / `cpu_baseline` / each secondary as scalars only.  Everything
+    else of `detail` (executed / valu_issue / clock / hbm / traffic_detail, per-rank arrays, sources, notes) lives in the side file."""
+    c = detail["config"]
+    line = {k: _sig(detail.get(k), 9) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_rank_min",
+                                                 "ms_per_step_rank_max", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": _short(c["workload"], 160), "units_per_gpu_per_step": c["units_per_gpu_per_step"],
+                      "units_whole_job_per_step": c.get("units_whole_job_per_step"), "ranks": c.get("ranks"),
+                      "collective_backend": c.get("collective_backend"), "exchange_impl": _short(c.get("exchange_impl"), 100),
+                      "constants_identical_on_all_ranks": c.get("constants_identical_on_all_ranks")}
+    line["roofline"] = compact_roofline(detail["roofline"])
+    rh = detail.get("roofline_hbm")
+    if rh and detail["roofline"].get("bound") != "hbm":  # the same kernel in the contract's HBM shape (not the binding bound)
+        line["roofline_hbm"] = {k: _sig(rh.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac")}
+    line["self_consistency_ok"] = detail.get("self_consistency_ok")
+    if "secondary" in detail:
+        sec = {}
+        for key, w in detail["secondary"].items():
+            s = {k: _sig(w.get(k), 9 if k in ("value", "ms_per_step") else 7) for k in SECONDARY_SCALARS}
+            r = w.get("roofline") or {}
+            s.update({"bound": r.get("bound"), "kernel": r.get("kernel"), "frac": _sig(r.get("frac")), "frac_at_measured_clock": _sig(r.get("frac_at_measured_clock")),
+                      "achieved": _sig(r.get("achieved")), "traffic_ratio": _sig(r.get("traffic_ratio"))})
+            if w.get("exchange_impl"):
+                s["exchange_impl"] = _short(w["exchange_impl"], 60)
+                s["units_whole_job_per_step"] = w.get("units_whole_job_per_step")
+            sec[key] = s
+        line["secondary"] = sec
+    if "secondary_timeout" in detail:
+        line["secondary_timeout"] = {k: detail["secondary_timeout"][k] for k in ("workload", "seconds")}
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": _short(cb["sample"], 120), "threads": cb.get("threads"), "value_1core": _sig(cb.get("value_1core")),
+                                "cpu": cb.get("cpu"), "parity_sample_ok": cb.get("parity_sample_ok"),
+                                "reference_cargo_bench": {"available": bool((cb.get("reference_cargo_bench") or {}).get("available")),
+                                                          "value": _sig((cb.get("reference_cargo_bench") or {}).get("value"))}}
+    line["detail_file"] = detail_file
+    return line
+
+
+def emit(detail, detail_path):
+    """write the full record to the side file, print the bounded line; a line over budget is a bug (tests assert the budget on
+    full synthetic and real lines) — should it ever happen the secondaries are cut to their headline pair rather than the line lost"""
+    written = None
+    for path in (detail_path, os.path.join("/tmp", "bench_detail.json")):
+        try:
+            with open(path, "w") as f:
+                json.dump(detail, f, indent=1)
+            written = path
+            break
+        except OSError:
+            continue
+    line = compact_line(detail, os.path.relpath(written, ROOT) if written and written.startswith(ROOT + os.sep) else written)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_BUDGET_BYTES and "secondary" in line:
+        line["secondary"] = {k: {"value": v["value"], "ms_per_step": v["ms_per_step"], "frac": v["frac"]} for k, v in line["secondary"].items()}
+        line["line_trimmed"] = True
+        text = json.dumps(line, separators=(",", ":"))
+    print(text, flush=True)
+    return line
+
+
+def primary_record_to_stderr(detail):
+    """the scaling curve is made of the primary alone: as soon as it is measured a minimal record goes to STDERR, so that a
+    driver-side kill during a secondary workload (not a hang the watchdog sees) still leaves the number in the captured tail"""
+    r = detail["roofline"]
+    rec = {"bench_primary": True, "metric": detail["metric"], "value": _sig(detail["value"], 9), "unit": detail["unit"], "n_gpus": detail["n_gpus"],
+           "steps": detail["steps"], "ms_per_step": _sig(detail["ms_per_step"], 9), "roofline_frac": _sig(r.get("frac")), "kernel": r.get("kernel")}
+    print("bench.py primary: " + json.dumps(rec, separators=(",", ":")), file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -892,7 +999,8 @@ def main():
                        "ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "input": "splitmix64 seed 0xc10d + rank, uniform mod p (SURVEY §8d)",
-                       "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical},
+                       "constants": "RCCL broadcast from rank 0 (identical to local derivation: %s)" % tables_identical,
+                       "constants_identical_on_all_ranks": bool(tables_identical)},
             "roofline": roofline,
             # the same kernel priced against the HBM roofline in the contract's shape (NOT the binding bound here)
             "roofline_hbm": ({"bound": "hbm", "achieved": roofline["hbm"]["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -904,6 +1012,7 @@ def main():
                       "note": "untimed launches of the same step before the W warm-up steps: brings an idle GPU's clocks to steady state; "
                               "4 + 4 more untimed steps carry the clock probe before and after the timed region"},
         }
+        primary_record_to_stderr(line)
     del W
     torch.cuda.empty_cache()
 
@@ -925,7 +1034,7 @@ def main():
                     line["secondary"] = secondary
                     line["secondary_timeout"] = {"workload": watch["key"], "seconds": args.secondary_timeout,
                                                  "note": "this secondary workload did not finish; the primary figures above are complete"}
-                    print(json.dumps(line), flush=True)
+                    emit(line, args.detail_file)
                 print("bench.py rank %d: secondary workload %r exceeded %d s — leaving" % (rank, watch["key"], args.secondary_timeout), file=sys.stderr, flush=True)
                 os._exit(0)
     if world > 1 and secondary_keys and args.secondary_timeout > 0:
@@ -978,7 +1087,7 @@ def main():
             if line["cpu_baseline"].get("parity_sample_ok") is False:
                 print("PARITY FAILURE: GPU output differs from the oracle: %s" % line["cpu_baseline"]["parity_samples"], file=sys.stderr)
                 sys.exit(3)
-        print(json.dumps(line))
+        emit(line, args.detail_file)
     if E._comm is not None:  # the library's communicator goes first, while every rank is still here
         torch.cuda.synchronize()
         E._comm.destroy()

@@ -25,21 +25,53 @@ def _free_port():
     return port
 
 
-def _one_json_line(out):
+LINE_BUDGET = 6000  # the driver keeps an 8 KB tail of stdout; round 4's 26 KB line could not be parsed
+
+
+def _scalars_only(obj, depth=0):
+    """the printed line nests at most: line -> roofline / config / cpu_baseline / secondary -> workload -> scalars (+ reference_cargo_bench)"""
+    for k, v in obj.items():
+        if isinstance(v, dict):
+            assert depth < 3, k
+            _scalars_only(v, depth + 1)
+        else:
+            assert v is None or isinstance(v, (bool, int, float, str)), (k, v)
+
+
+def _one_json_line(out, want_detail=False):
+    """the ONE line on stdout: bounded in length, scalars only; the full record (nested models, per-rank arrays, sources, notes) is in
+    the side file the line names"""
     lines = [l for l in out.decode().splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.decode()
-    return json.loads(lines[0])
+    assert len(lines[0]) < LINE_BUDGET, len(lines[0])
+    d = json.loads(lines[0])
+    _scalars_only(d)
+    assert "line_trimmed" not in d and d["detail_file"] == "bench_detail.json"
+    if not want_detail:
+        return d
+    full = json.load(open(os.path.join(ROOT, d["detail_file"])))
+    assert full["value"] == pytest.approx(d["value"], rel=1e-7) and full["n_gpus"] == d["n_gpus"] and full["config"]["workload"].startswith(d["config"]["workload"].rstrip("."))
+    for k, v in d["roofline"].items():  # the line's roofline = the record's top-level scalars
+        assert full["roofline"][k] == (pytest.approx(v, rel=1e-6) if isinstance(v, float) else v), k
+    for key, w in d.get("secondary", {}).items():
+        fw = full["secondary"][key]
+        assert fw["value"] == pytest.approx(w["value"], rel=1e-7) and fw["roofline"]["kernel"] == w["kernel"] and fw["self_consistency_ok"] == w["self_consistency_ok"]
+        assert w["frac"] == pytest.approx(fw["roofline"]["frac"], rel=1e-6)
+    return d, full
 
 
 def test_bench_single_gpu_json_line(gpu_ctx):
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                                    "--log2n", "16", "--no-cpu-baseline", "--no-secondary"], cwd=ROOT, timeout=600)
-    d = _one_json_line(out)
+    d, full = _one_json_line(out, want_detail=True)
     for k in REQUIRED:
-        assert k in d, k
+        assert k in d and k in full, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["self_consistency_ok"] is True
     assert d["value"] > 1e6 and d["scaling"] == "weak" and d["vs_baseline"] is None
-    r = d["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):  # the contract's roofline keys, on the line itself
+        assert k in d["roofline"], k
+    assert d["roofline"]["frac"] == pytest.approx(d["roofline"]["achieved"] / d["roofline"]["peak"], rel=1e-5)
+    r = full["roofline"]
     assert r["hbm"]["frac"] < 0.05 and r["hbm_frac"] == r["hbm"]["frac"]
     _check_roofline_scalars(r)
     _check_clock(r)
@@ -81,9 +113,15 @@ def test_bench_default_line_carries_the_secondary_workloads(gpu_ctx):
     self-consistency check, roofline, measured clock and (N = 1) oracle check of a sample.  Scaled down here."""
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "15",
                                    "--secondary-log2n", "14"], cwd=ROOT, timeout=900, stderr=subprocess.DEVNULL)
-    d = _one_json_line(out)
-    for k in REQUIRED:
-        assert k in d, k
+    line, d = _one_json_line(out, want_detail=True)  # (the length budget and scalars-only shape are asserted on the real line in there)
+    for k in REQUIRED + ["cpu_baseline", "secondary"]:
+        assert k in d and k in line, k
+    assert sorted(line["secondary"]) == sorted(d["secondary"]) and line["cpu_baseline"]["parity_sample_ok"] is True
+    for k in ("value", "unit", "cores", "kind", "sample"):  # the contract's cpu_baseline keys, on the line itself
+        assert line["cpu_baseline"][k] is not None, k
+    assert line["cpu_baseline"]["reference_cargo_bench"]["available"] in (True, False)
+    for w in line["secondary"].values():
+        assert w["self_consistency_ok"] is True and w["parity_sample_ok"] is True and 0 < w["frac"] <= 1 and w["value"] > 1e6
     assert "BASELINE configs[1]" in d["config"]["workload"] and d["self_consistency_ok"] is True
     sec = d["secondary"]
     assert sorted(sec) == ["encrypt", "extract", "forest", "openings", "sponge42", "tree"]
@@ -157,8 +195,9 @@ def test_bench_rccl_backend_single_rank(gpu_ctx):
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
                                    "--log2n", "14", "--secondary-log2n", "12", "--no-cpu-baseline"], cwd=ROOT, env=env, timeout=600,
                                   stderr=subprocess.DEVNULL)
-    d = _one_json_line(out)
-    assert d["n_gpus"] == 1 and d["self_consistency_ok"] is True
+    line, d = _one_json_line(out, want_detail=True)
+    assert d["n_gpus"] == 1 and d["self_consistency_ok"] is True and line["config"]["constants_identical_on_all_ranks"] is True
+    assert "inside libposeidon252_hip.so" in line["secondary"]["tree"]["exchange_impl"]
     assert "identical to local derivation: True" in d["config"]["constants"]
     # the secondary tree takes the sharded path whenever a process group exists: subtree root -> RCCL all-gather (of one
     # root here) -> top levels — the collective of BASELINE configs[4] on the real backend, INSIDE the library (VERDICT r3
@@ -189,7 +228,8 @@ def test_bench_two_ranks_share_gpu_gloo(gpu_ctx):
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--log2n", "16", "--secondary-log2n", "12"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.DEVNULL)
-    d = _one_json_line(out)
+    line, d = _one_json_line(out, want_detail=True)
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["value"] == pytest.approx(2 * line["config"]["units_per_gpu_per_step"] * 3 / (line["ms_per_step"] * 3e-3), rel=1e-6)
     assert d["n_gpus"] == 2 and d["self_consistency_ok"] is True and "cpu_baseline" not in d
     assert "identical to local derivation: True" in d["config"]["constants"]
     # whole-job value = 2 ranks x units / max-over-ranks time
@@ -222,7 +262,9 @@ def test_bench_eight_ranks_rehearsal_of_the_driver_command(gpu_ctx, oracle_mod):
         env.pop(key, None)
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
                                    "--log2n", "12", "--secondary-log2n", str(2 * k - 4)], cwd=ROOT, env=env, timeout=1500, stderr=subprocess.DEVNULL)
-    d = _one_json_line(out)
+    line, d = _one_json_line(out, want_detail=True)  # the 8-rank line (per-rank arrays live in the side file) stays inside the budget too
+    assert line["n_gpus"] == 8 and line["config"]["ranks"] == 8 and line["ms_per_step_rank_min"] <= line["ms_per_step_rank_max"]
+    assert line["secondary"]["tree"]["units_whole_job_per_step"] == 8 * ((4 ** k - 1) // 3) + 3
     assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and d["self_consistency_ok"] is True and "cpu_baseline" not in d
     assert d["value"] == pytest.approx(8 * d["config"]["units_per_gpu_per_step"] * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
     assert len(d["ms_per_step_per_rank"]) == 8 and d["ms_per_step_rank_min"] <= d["ms_per_step_rank_max"] <= d["ms_per_step"] * 1.001
@@ -253,10 +295,17 @@ def test_bench_watchdog_prints_the_line_when_a_secondary_hangs(gpu_ctx):
            "--warmup", "1", "--log2n", "12", "--secondary-log2n", "8", "--secondary-timeout", "8"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, timeout=600, capture_output=True)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    d = _one_json_line(r.stdout)
+    d, full = _one_json_line(r.stdout, want_detail=True)  # (the watchdog prints the same bounded line)
     assert d["n_gpus"] == 2 and d["value"] > 1e5 and d["self_consistency_ok"] is True
     assert d["secondary_timeout"]["workload"] == "sponge42" and sorted(d["secondary"]) == ["forest", "tree"]
-    assert d["secondary"]["tree"]["self_consistency_ok"] is True
+    assert d["secondary"]["tree"]["self_consistency_ok"] is True and full["secondary_timeout"]["workload"] == "sponge42"
+    # the primary's minimal record went to stderr as soon as it was measured — a kill during a secondary
+    # (which no watchdog sees) still leaves the scaling number in the captured tail
+    prim = [l for l in r.stderr.decode().splitlines() if l.startswith("bench.py primary: ")]
+    assert len(prim) == 1
+    rec = json.loads(prim[0][len("bench.py primary: "):])
+    assert rec["n_gpus"] == 2 and rec["value"] == pytest.approx(d["value"], rel=1e-6) and rec["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=1e-6)
+    assert rec["roofline_frac"] == pytest.approx(d["roofline"]["frac"], rel=1e-5)
 
 
 def test_bench_gpus_flag_launches_the_ranks_itself(gpu_ctx):

@@ -82,3 +82,67 @@ def test_cpu_baseline_plumbing_probes_at_run_time():
     if not rc["available"]:
         assert rc["why"].startswith("not on this box: ") and all(name in rc["why"] for name, v in rc["probe"].items() if not v)
     assert 1 <= bench.usable_cpus() <= (os.cpu_count() or 1)
+
+
+def _full_record():
+    """round 4's real 26 KB record (all six secondaries, cpu_baseline): the one the driver could NOT parse"""
+    import json
+    return json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+
+
+def test_printed_line_fits_the_drivers_tail_and_is_scalars_only(tmp_path, capsys):
+    """BENCH_r04.json had parsed = null because the line was 26,409 bytes against the driver's 8 KB tail.  The
+    printed line is now scalars only, under 6,000 bytes with all six secondaries and the cpu_baseline; the full record goes to a side file."""
+    import json
+    full = _full_record()
+    assert len(json.dumps(full)) > 20000
+    line = bench.emit(full, str(tmp_path / "bench_detail.json"))
+    out = capsys.readouterr().out
+    assert out.count("\n") == 1 and len(out) < bench.LINE_BUDGET_BYTES == 6000 and json.loads(out) == line and "line_trimmed" not in line
+    assert json.load(open(tmp_path / "bench_detail.json")) == full  # nothing is lost: every nested model, source and note is in the side file
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == (pytest.approx(full[k], rel=1e-8) if isinstance(full[k], float) else full[k]), k
+    assert line["config"]["workload"] == full["config"]["workload"] and line["config"]["units_per_gpu_per_step"] == 1 << 20
+    r = line["roofline"]
+    assert set(r) == set(bench.ROOFLINE_SCALARS) and all(v is None or isinstance(v, (int, float, str)) for v in r.values())
+    assert r["bound"] == "valu-int32-mac" and r["kernel"] == "k_merkle4" and r["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-6)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-5) and r["traffic"] == pytest.approx(full["roofline"]["traffic"], rel=1e-6)
+    assert sorted(line["secondary"]) == ["encrypt", "extract", "forest", "openings", "sponge42", "tree"]
+    for key, w in line["secondary"].items():
+        assert all(v is None or isinstance(v, (bool, int, float, str)) for v in w.values()), key
+        assert w["value"] == pytest.approx(full["secondary"][key]["value"], rel=1e-8) and w["frac"] == pytest.approx(full["secondary"][key]["roofline"]["frac"], rel=1e-6)
+        assert w["kernel"] == full["secondary"][key]["roofline"]["kernel"] and w["self_consistency_ok"] is True and w["parity_sample_ok"] is True
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 16 and cb["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-6) and cb["sample"]
+    assert cb["reference_cargo_bench"] == {"available": False, "value": None} and cb["parity_sample_ok"] is True
+
+
+def test_eight_rank_line_with_long_strings_stays_inside_the_budget(tmp_path, capsys):
+    """the N = 8 line: per-rank arrays and the exchange descriptions must not push it past the budget either (they live in the side file)"""
+    import copy
+    import json
+    full = copy.deepcopy(_full_record())
+    full.pop("cpu_baseline")
+    full["n_gpus"] = 8
+    full["ms_per_step_per_rank"] = [2.123456789012] * 8
+    full["config"].update(ranks=8, collective_backend="nccl", units_whole_job_per_step=8 << 20)
+    for w in full["secondary"].values():
+        w["ms_per_step_per_rank"] = [12.123456789012] * 8
+        w["exchange_impl"] = "ncclAllGather inside libposeidon252_hip.so (p252_merkle4_tree_sharded_device), on the launch stream; " + "x" * 300
+        w["workload"] += " = 2^27-leaf tree sharded across 8 GPUs (BASELINE configs[4])" + " padding" * 40
+        w["root_mont_hex"] = "f" * 64
+    full["secondary_timeout"] = {"workload": "extract", "seconds": 240, "note": "n" * 500}
+    line = bench.emit(full, str(tmp_path / "d.json"))
+    out = capsys.readouterr().out
+    assert len(out) < bench.LINE_BUDGET_BYTES and "line_trimmed" not in line and line["secondary_timeout"] == {"workload": "extract", "seconds": 240}
+    assert "ms_per_step_per_rank" not in json.dumps(line) and line["n_gpus"] == 8 and line["config"]["ranks"] == 8
+
+
+def test_primary_record_goes_to_stderr_at_once(capsys):
+    """a minimal primary record on stderr as soon as the primary is measured"""
+    import json
+    bench.primary_record_to_stderr(_full_record())
+    err = capsys.readouterr().err
+    assert err.startswith("bench.py primary: ") and len(err) < 400
+    rec = json.loads(err[len("bench.py primary: "):])
+    assert rec["value"] == pytest.approx(4.945e8, rel=1e-3) and rec["roofline_frac"] == pytest.approx(0.7705, rel=1e-3) and rec["n_gpus"] == 1
