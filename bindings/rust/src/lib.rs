@@ -179,6 +179,20 @@ impl HashBatch {
         out
     }
 
+    /// `Hash::digest_truncated` per item (src/hash.rs:203-210) in ONE kernel launch: the raw limbs the reference hands to
+    /// `JubJubScalar::from_raw` (src/hash.rs:180) — canonical value & (2^250 - 1), truncated by the digest kernel's output stage.
+    pub fn digest_truncated_raw(&self, input: &[BlsScalar]) -> Vec<[u64; 4]> {
+        assert_eq!(input.len() % self.item_len, 0, "io-pattern should be valid");
+        let n = input.len() / self.item_len;
+        let mut out = vec![[0u64; 4]; n * self.output_len];
+        let rc = unsafe {
+            p252_hash_batch_truncated(self.ctxs[0].0, self.tag.0.as_ptr(), input.as_ptr() as *const u64, self.item_len, self.output_len,
+                                      out.as_mut_ptr() as *mut u64, n)
+        };
+        self.ctxs[0].check(rc);
+        out
+    }
+
     /// Root of the arity-4 tree over `Hash::digest(Domain::Merkle4, ..)` nodes (empty slots = zero scalar).  With
     /// several devices `leaves.len()` must be `devices * 4^k` (one complete subtree per GPU, roots gathered on the host).
     pub fn merkle4_root(&self, leaves: &[BlsScalar]) -> BlsScalar {

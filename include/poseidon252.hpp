@@ -136,7 +136,13 @@ class Hash {
     void update(const std::vector<BlsScalar>& input) { update(input.data(), input.size()); }
 
     // hash.rs:128-155.  Throws IoPatternError where the reference panics.
-    std::vector<BlsScalar> finalize() const {
+    std::vector<BlsScalar> finalize() const { return run(false); }
+    // hash.rs:164-183: the digest kernel's output stage canonicalises, masks to 250 bits and stores the raw limbs
+    // JubJubScalar::from_raw receives — one launch (p252_hash_batch_truncated)
+    std::vector<JubJubRaw> finalize_truncated() const { return run(true); }
+
+  private:
+    std::vector<BlsScalar> run(bool truncated) const {
         std::vector<std::size_t> lens;
         std::size_t total = 0;
         for (auto& c : input_) {
@@ -149,17 +155,13 @@ class Hash {
         msg.reserve(total);
         for (auto& c : input_) msg.insert(msg.end(), c.first, c.first + c.second);
         std::vector<BlsScalar> out(output_len_);
-        detail::check(p252_hash_batch(ctx_.get(), tag.data(), msg[0].data(), total, output_len_, out[0].data(), 1), ctx_.get(),
-                      "Hash::finalize");
+        detail::check((truncated ? p252_hash_batch_truncated : p252_hash_batch)(ctx_.get(), tag.data(), msg[0].data(), total, output_len_,
+                                                                                out[0].data(), 1),
+                      ctx_.get(), truncated ? "Hash::finalize_truncated" : "Hash::finalize");
         return out;
     }
-    // hash.rs:164-183
-    std::vector<JubJubRaw> finalize_truncated() const {
-        const std::vector<BlsScalar> bls = finalize();
-        std::vector<JubJubRaw> out(bls.size());
-        detail::check(p252_truncate250(bls[0].data(), out[0].data(), bls.size()), nullptr, "truncate");
-        return out;
-    }
+
+  public:
     // hash.rs:191-195, 203-210
     static std::vector<BlsScalar> digest(Domain domain, const std::vector<BlsScalar>& input) {
         Hash h(domain);
@@ -209,10 +211,24 @@ class HashBatch {
                           ctx_.get(), "HashBatch::digest");
         return out;
     }
+    // Hash::digest_truncated per item (hash.rs:203-210), truncated inside the digest kernel: one launch
+    std::vector<JubJubRaw> digest_truncated(const std::vector<BlsScalar>& input) const {
+        if (item_len_ == 0 || input.size() % item_len_) throw std::invalid_argument("HashBatch::digest_truncated: ragged input");
+        const std::size_t n = input.size() / item_len_;
+        std::vector<JubJubRaw> out(n * output_len_);
+        if (n)
+            detail::check(p252_hash_batch_truncated(ctx_.get(), tag_.data(), input[0].data(), item_len_, output_len_, out[0].data(), n),
+                          ctx_.get(), "HashBatch::digest_truncated");
+        return out;
+    }
     // device buffers, asynchronous on `stream` (a hipStream_t)
     void digest_device(const void* d_in, void* d_out, std::size_t n, void* stream = nullptr) const {
         detail::check(p252_hash_batch_device(ctx_.get(), tag_.data(), d_in, item_len_, output_len_, d_out, n, stream), ctx_.get(),
                       "HashBatch::digest_device");
+    }
+    void digest_truncated_device(const void* d_in, void* d_out_raw, std::size_t n, void* stream = nullptr) const {
+        detail::check(p252_hash_batch_truncated_device(ctx_.get(), tag_.data(), d_in, item_len_, output_len_, d_out_raw, n, stream),
+                      ctx_.get(), "HashBatch::digest_truncated_device");
     }
 
   private:

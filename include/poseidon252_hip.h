@@ -34,8 +34,13 @@
  * one wave's latency; such batches run kernels that spread each state over a group of lanes (0.12 ms per permutation
  * instead of 0.17).  Results are the same bytes whichever kernel runs.
  *
- * Threading: a context is bound to one device and used by one thread at a time; distinct contexts
- * are independent.  Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
+ * Threading and streams: a context is bound to one device and its functions are CALLED by one thread at a time; distinct
+ * contexts are independent.  The `*_device` entry points only enqueue on the stream they are given, and calls on DIFFERENT
+ * streams of one context may overlap on the device: every root-only tree / forest build (d_levels == NULL) ping-pongs its
+ * levels in scratch owned by the context PER STREAM (up to four streams at once; a fifth takes over the least recently used
+ * scratch behind an event — never concurrently), and a communicator's buffers are handed from one stream to the next behind
+ * an event as well.  The one context-wide piece of state is the encryption call table: p252_{encrypt,decrypt}_batch_device
+ * with another (variant, len) than the previous call drains the device before replacing it.  Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
  * or the p252_*_multi entry points below, which take the array of contexts and shard inside the library; batches
  * shard with no inter-GPU dependence.
  */
@@ -58,8 +63,13 @@ extern "C" {
  *   6  + the RCCL communicator (p252_comm_*), p252_merkle4_tree_sharded_device, p252_merkle4_tree_multi_device_resident,
  *      p252_merkle4_forest[_device], p252_merkle2_forest_device, p252_merkle{4,2}_openings_device, p252_merkle{4,2}_depth,
  *      p252_merkle2_path_batch_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
- *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on) */
-#define P252_ABI_VERSION 6
+ *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on)
+ *   7  + p252_hash_batch_truncated[_device] (finalize_truncated fused into the digest kernels' output stage: one launch),
+ *      p252_wipe, p252_scratch_residue; the host-buffer p252_{encrypt,decrypt}_batch and p252_destroy clear the library-owned
+ *      copies of what they were handed; root-only tree / forest builds on DIFFERENT streams of one context no longer share
+ *      scratch; p252_merkle4_tree_multi_device accepts any array of contexts again (as ABI 5 did) and makes no communicator for
+ *      a single context */
+#define P252_ABI_VERSION 7
 
 #define P252_OK 0
 #define P252_ERR_IO_PATTERN_VIOLATION (-1) /* dusk_poseidon::Error::IOPatternViolation, src/error.rs:12-14 */
@@ -100,6 +110,10 @@ int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, siz
  * P252_ERR_INVALID_IO_PATTERN. */
 int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
                     size_t out_len, uint64_t* out, size_t n);
+/* the same with Hash::finalize_truncated's outputs (hash.rs:164-183): out_raw = n x out_len x 4 raw limbs, canonical value
+ * & (2^250 - 1), truncated inside the digest kernel (see p252_hash_batch_truncated_device) */
+int p252_hash_batch_truncated(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len,
+                              size_t out_len, uint64_t* out_raw, size_t n);
 /* Arity-4 Merkle tree over Hash::digest(Domain::Merkle4, [c0,c1,c2,c3]) nodes; empty child slots
  * are the zero scalar (hash.rs:22-26).  Levels are built while more than one node remains (a single
  * leaf is its own root; a 4^k-leaf tree costs exactly k levels).  `levels`
@@ -135,12 +149,29 @@ int p252_host_unregister(void* p);
 int p252_permute_batch_device(p252_ctx* ctx, const void* d_states, void* d_out, size_t n, void* hip_stream);
 int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
                            size_t out_len, void* d_out, size_t n, void* hip_stream);
-/* d_levels may be NULL (context-owned scratch is used); d_root receives 1 scalar. */
+/* Hash::finalize_truncated / digest_truncated (hash.rs:164-183, 203-210) for the whole batch in ONE launch: the same kernels
+ * with a truncating output stage — every squeezed scalar is canonicalised (Montgomery form dropped), masked to its low 250 bits
+ * and stored as the raw limbs JubJubScalar::from_raw receives; identical to p252_hash_batch_device followed by
+ * p252_truncate250_device without the second launch and the 64 B / scalar round trip through HBM. */
+int p252_hash_batch_truncated_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
+                                     size_t out_len, void* d_out_raw, size_t n, void* hip_stream);
+/* d_levels may be NULL: the levels then ping-pong in context-owned scratch — one pair per caller stream, so builds queued on
+ * different streams of one context never share it (see "Threading and streams"); d_root receives 1 scalar. */
 int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
                              void* d_root, void* d_levels, void* hip_stream);
 int p252_merkle2_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
                              void* d_root, void* d_levels, void* hip_stream);
 int p252_sync(p252_ctx* ctx, void* hip_stream);
+/* Secret hygiene (the reference builds with `zeroize`, Cargo.toml:14; dusk-safe zeroizes a finished sponge).  The kernels keep
+ * sponge states in registers only.  What a HOST-buffer call leaves behind is the library's copy of the caller's arrays — the
+ * context's device scratch and the page-locked staging lanes: p252_encrypt_batch / p252_decrypt_batch clear what they used
+ * before returning, p252_destroy clears everything before freeing it, and p252_wipe clears every buffer the context owns on
+ * demand (it waits for the device first; hashing calls do not wipe — their inputs are public).  `_device` callers own their
+ * buffers; the only thing such a call leaves in the context is the (variant, len) call table, which holds no secret. */
+int p252_wipe(p252_ctx* ctx);
+/* diagnostics: the number of non-zero bytes in every scratch buffer the context owns (device scratch, level scratch, the
+ * encryption call table, staging lanes on both sides) — 0 right after p252_wipe or a host-buffer encrypt / decrypt call */
+int p252_scratch_residue(p252_ctx* ctx, uint64_t* nonzero_bytes);
 
 /* ---- SURVEY §8(f) "next" rows ---- */
 /* finalize_truncated's post-processing (hash.rs:164-183) on n device-resident BlsScalars: canonical
@@ -273,12 +304,18 @@ int p252_merkle4_tree_multi(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t 
  * over the contexts is created on the first such call — or beforehand with p252_comm_create_all — and kept; it is destroyed
  * with its contexts) and every device hashes the top levels, so nothing but the final 32 bytes crosses PCIe.  Contexts
  * that share a device (RCCL wants one device per rank: the single-GPU test configuration), or P252_MULTI_HOST_GATHER=1:
- * the roots are gathered through the host and the top levels run on ctxs[0]. */
+ * the roots are gathered through the host and the top levels run on ctxs[0].
+ * ANY array of contexts is accepted, call after call (ctxs[0..8), then ctxs[0..4), a permutation ...): a communicator this
+ * entry point made itself over another array is torn down and re-made for the array at hand (communicator creation costs
+ * ~0.1-1 s: keep the array stable, or make the communicator once with p252_comm_create_all); contexts that sit in a
+ * communicator the CALLER made over another array, and a failing lazy creation, fall back to the host gather.  n_ctx == 1
+ * makes no communicator at all. */
 int p252_merkle4_tree_multi_device(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,
                                    size_t leaves_per_ctx, uint64_t root[4]);
 /* the RCCL path only, fully asynchronous and device-resident: on return the work is queued on hip_streams[t] (NULL: the
  * default streams) and d_root_out[t] (32 bytes on ctxs[t]'s device; entries, or the array, may be NULL) will hold the
- * root on EVERY device — no host round trip.  P252_ERR_COMM when the contexts cannot form a communicator. */
+ * root on EVERY device — no host round trip.  P252_ERR_COMM when the contexts cannot form a communicator (shared device,
+ * P252_MULTI_HOST_GATHER=1, contexts of a caller-made communicator over another array, RCCL refusing): there is no host path here. */
 int p252_merkle4_tree_multi_device_resident(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,
                                             size_t leaves_per_ctx, void* const* d_root_out, void* const* hip_streams);
 
@@ -290,7 +327,12 @@ int p252_merkle4_tree_multi_device_resident(p252_ctx* const* ctxs, size_t n_ctx,
  * rank calls p252_comm_create_rank with its own context (collective: returns when all `world` ranks have called).
  * One process, several GPUs: p252_comm_create_all over contexts on DISTINCT devices.  A context belongs to at most one
  * communicator; destroy the communicator before its context.  xGMI note: these messages are world x 32 bytes — latency
- * only. ---- */
+ * only.  Creation and the sharded build are COLLECTIVE: every rank calls them, in the same order.  Every device allocation
+ * of a rank happens before its first collective, so a rank that cannot allocate fails before its peers wait for it; a rank
+ * whose subtree build fails later still enters the all-gather (contributing an all-ones root, which is no BlsScalar) and
+ * returns its error — peers are never left blocked on the stream, and the job must treat one rank's error as the failure of
+ * the build, as with any collective.  Builds of one communicator queued on different streams run one after the other
+ * (event-ordered on the device), never concurrently. ---- */
 int p252_comm_unique_id(void* id_out, size_t len /* = P252_COMM_ID_BYTES */);
 int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, int world, p252_comm** out);
 int p252_comm_create_all(p252_ctx* const* ctxs, size_t n_ctx, p252_comm** comms_out /* [n_ctx] */);

@@ -17,13 +17,15 @@ HIPCC_FLAGS = [
 ]
 SOURCES = ["kernels.hip", "openings.hip", "merkle2.hip", "api.cpp", "comm.cpp"]
 # comm.cpp: the RCCL communicator of the multi-GPU entry points (ncclBroadcast of the constants, ncclAllGather of subtree roots)
-LINK_FLAGS = ["-L/opt/rocm/lib", "-lrccl"]
+# (ROCM_PATH / HIP_PATH name the ROCm prefix when it is not /opt/rocm — ADVICE r4)
+ROCM = os.environ.get("ROCM_PATH") or os.environ.get("HIP_PATH") or "/opt/rocm"
+LINK_FLAGS = ["-L" + os.path.join(ROCM, "lib"), "-lrccl"]
 HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp", "ctx.hpp", "openings.h",
            os.path.join("..", "..", "include", "poseidon252_hip.h")]
 
 
 def _hipcc():
-    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+    for cand in (os.environ.get("HIPCC"), os.path.join(ROCM, "bin", "hipcc"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
             return cand
     return "hipcc"

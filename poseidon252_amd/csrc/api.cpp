@@ -48,6 +48,38 @@ int p252host::ensure(p252_ctx* ctx, void** buf, size_t* cap, size_t need) {
     return P252_OK;
 }
 
+int p252host::level_set(p252_ctx* ctx, hipStream_t st, size_t need0, size_t need1, p252_ctx::LevelSet** out) {
+    p252_ctx::LevelSet* set = nullptr;
+    for (auto& s : ctx->lvl)
+        if (s.st == st) set = &s;
+    if (!set && ctx->lvl.size() < p252_ctx::MAX_LEVEL_SETS) {
+        if (ctx->lvl.capacity() < p252_ctx::MAX_LEVEL_SETS) ctx->lvl.reserve(p252_ctx::MAX_LEVEL_SETS);  // (pointers into it stay valid)
+        ctx->lvl.emplace_back();
+        set = &ctx->lvl.back();
+        set->st = st;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&set->done, hipEventDisableTiming));
+    }
+    if (!set) {  // more streams than pairs: take over the least recently used pair, behind its last build
+        set = &ctx->lvl[0];
+        for (auto& s : ctx->lvl)
+            if (s.stamp < set->stamp) set = &s;
+        if (set->stamp) HIP_TRY(ctx, hipStreamWaitEvent(st, set->done, 0));
+        set->st = st;
+    }
+    // (growing frees the old buffer: hipFree waits for the device, so no queued launch still reads it)
+    int rc = ensure(ctx, &set->buf[0], &set->cap[0], need0);
+    if (rc == P252_OK) rc = ensure(ctx, &set->buf[1], &set->cap[1], need1);
+    if (rc) return rc;
+    *out = set;
+    return P252_OK;
+}
+
+int p252host::level_set_done(p252_ctx* ctx, p252_ctx::LevelSet* set) {
+    set->stamp = ++ctx->lvl_clock;
+    HIP_TRY(ctx, hipEventRecord(set->done, set->st));
+    return P252_OK;
+}
+
 const std::vector<int32_t>& p252host::host_tables() {
     static const std::vector<int32_t> tab = [] {
         HadesTables T;
@@ -88,11 +120,63 @@ static int for_each_ctx(p252_ctx* const* ctxs, size_t n_ctx, F&& f) {
     return P252_OK;
 }
 
+// ---- secret hygiene (the reference builds its scalars with `zeroize`, Cargo.toml:14, and dusk-safe zeroizes the sponge state
+// when a sponge finishes; src/encryption.rs:62-95 hands shared secrets, nonces and plaintexts through it).  The kernels keep
+// every sponge state in registers; what outlives a HOST-buffer encrypt / decrypt call is the library's own copy of the
+// caller's arrays: the context's device scratch and the page-locked staging lanes.  wipe_span / wipe_lanes clear exactly
+// those at the end of such a call; wipe_all clears every buffer the context owns (p252_wipe, p252_destroy). ----
+static hipError_t wipe_span(void* d, size_t bytes) { return (d && bytes) ? hipMemsetAsync(d, 0, bytes, nullptr) : hipSuccess; }
+
+static hipError_t wipe_lanes(p252_ctx* ctx) {
+    hipError_t first = hipSuccess;
+    for (auto& l : ctx->lanes)
+        for (auto& sl : l.slot) {
+            if (sl.h_in) std::memset(sl.h_in, 0, sl.in_cap);
+            if (sl.h_out) std::memset(sl.h_out, 0, sl.out_cap);
+            hipError_t e = wipe_span(sl.d_in, sl.in_cap);
+            if (e == hipSuccess) e = wipe_span(sl.d_out, sl.out_cap);
+            if (e != hipSuccess && first == hipSuccess) first = e;
+        }
+    return first;
+}
+
+static hipError_t wipe_all(p252_ctx* ctx) {
+    hipError_t e = hipDeviceSynchronize();  // nothing queued may still read or write what is cleared below
+    auto keep = [&](hipError_t r) {
+        if (r != hipSuccess && e == hipSuccess) e = r;
+    };
+    keep(wipe_span(ctx->d_in, ctx->d_in_cap));
+    keep(wipe_span(ctx->d_out, ctx->d_out_cap));
+    for (auto& set : ctx->lvl)
+        for (int i = 0; i < 2; ++i) keep(wipe_span(set.buf[i], set.cap[i]));
+    keep(wipe_span(ctx->d_prog, ctx->d_prog_cap));
+    ctx->prog_variant = -1;  // (the call table is gone: the next encrypt / decrypt uploads it again)
+    ctx->prog_len = 0;
+    keep(wipe_lanes(ctx));
+    keep(hipStreamSynchronize(nullptr));
+    return e;
+}
+
+// non-zero bytes of a device buffer, read back 16 MiB at a time (diagnostics only)
+static hipError_t count_nonzero_device(const void* d, size_t bytes, uint64_t* total) {
+    if (!d || !bytes) return hipSuccess;
+    std::vector<uint64_t> host((size_t)2 << 20);
+    for (size_t off = 0; off < bytes; off += host.size() * 8) {
+        const size_t cnt = bytes - off < host.size() * 8 ? bytes - off : host.size() * 8;
+        host[(cnt - 1) / 8] = 0;
+        const hipError_t e = hipMemcpy(host.data(), static_cast<const char*>(d) + off, cnt, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(host.data());
+        for (size_t i = 0; i < cnt; ++i) *total += b[i] != 0;
+    }
+    return hipSuccess;
+}
+
 extern "C" {
 
 int p252_abi_version(void) { return P252_ABI_VERSION; }
 
-const char* p252_version(void) { return "poseidon252_hip 0.6 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
+const char* p252_version(void) { return "poseidon252_hip 0.7 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
 
 int p252_device_count(void) {
     int n = 0;
@@ -134,11 +218,15 @@ void p252_destroy(p252_ctx* ctx) {
     if (!ctx) return;
     release_ctx_comm(ctx);
     (void)hipSetDevice(ctx->device);
+    (void)wipe_all(ctx);  // nothing a call left in the context's scratch or staging survives it (zeroize, Cargo.toml:14)
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
-    for (int i = 0; i < 2; ++i)
-        if (ctx->d_lvl[i]) (void)hipFree(ctx->d_lvl[i]);
+    for (auto& s : ctx->lvl) {
+        for (int i = 0; i < 2; ++i)
+            if (s.buf[i]) (void)hipFree(s.buf[i]);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
     for (int i = 0; i < 3; ++i)
         if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
     if (ctx->d_prog) (void)hipFree(ctx->d_prog);
@@ -168,6 +256,33 @@ int p252_sync(p252_ctx* ctx, void* hip_stream) {
     return P252_OK;
 }
 
+int p252_wipe(p252_ctx* ctx) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, wipe_all(ctx));
+    return P252_OK;
+}
+
+int p252_scratch_residue(p252_ctx* ctx, uint64_t* nonzero_bytes) {
+    if (!ctx || !nonzero_bytes) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "scratch_residue: NULL argument");
+    *nonzero_bytes = 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, count_nonzero_device(ctx->d_in, ctx->d_in_cap, nonzero_bytes));
+    HIP_TRY(ctx, count_nonzero_device(ctx->d_out, ctx->d_out_cap, nonzero_bytes));
+    for (auto& set : ctx->lvl)
+        for (int i = 0; i < 2; ++i) HIP_TRY(ctx, count_nonzero_device(set.buf[i], set.cap[i], nonzero_bytes));
+    HIP_TRY(ctx, count_nonzero_device(ctx->d_prog, ctx->d_prog_cap, nonzero_bytes));
+    for (auto& l : ctx->lanes)
+        for (auto& sl : l.slot) {
+            HIP_TRY(ctx, count_nonzero_device(sl.d_in, sl.in_cap, nonzero_bytes));
+            HIP_TRY(ctx, count_nonzero_device(sl.d_out, sl.out_cap, nonzero_bytes));
+            for (size_t i = 0; sl.h_in && i < sl.in_cap; ++i) *nonzero_bytes += static_cast<const unsigned char*>(sl.h_in)[i] != 0;
+            for (size_t i = 0; sl.h_out && i < sl.out_cap; ++i) *nonzero_bytes += static_cast<const unsigned char*>(sl.h_out)[i] != 0;
+        }
+    return P252_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // device-buffer entry points
 // ------------------------------------------------------------------------------------------
@@ -181,8 +296,10 @@ int p252_permute_batch_device(p252_ctx* ctx, const void* d_states, void* d_out, 
     return P252_OK;
 }
 
-int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
-                           size_t out_len, void* d_out, size_t n, void* hip_stream) {
+// trunc250: Hash::finalize_truncated (hash.rs:164-183) — the digest kernels' output stage canonicalises, masks to 250 bits and
+// stores the raw limbs JubJubScalar::from_raw receives: one launch, no BlsScalar round trip through HBM
+static int hash_batch_device_impl(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
+                                  size_t out_len, void* d_out, size_t n, void* hip_stream, bool trunc250) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     // dusk-safe rejects io-patterns with an empty absorb or squeeze -> Hash::finalize panics (hash.rs:134-137)
     if (in_len == 0 || out_len == 0)
@@ -195,12 +312,22 @@ int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_i
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (in_len == 4 && out_len == 1)
-        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, tag_arg(tag), d_in, 4 * n, d_out, n, st));
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, tag_arg(tag), d_in, 4 * n, d_out, n, st, 4, 0, trunc250));
     else if (in_len == 2 && out_len == 1)  // Merkle2-shaped digests take the single-permutation kernel too
-        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, tag_arg(tag), d_in, 2 * n, d_out, n, st, 2));
+        HIP_TRY(ctx, launch_merkle4(ctx->d_tab, tag_arg(tag), d_in, 2 * n, d_out, n, st, 2, 0, trunc250));
     else
-        HIP_TRY(ctx, launch_sponge(ctx->d_tab, tag_arg(tag), d_in, (unsigned)in_len, (unsigned)out_len, d_out, n, st));
+        HIP_TRY(ctx, launch_sponge(ctx->d_tab, tag_arg(tag), d_in, (unsigned)in_len, (unsigned)out_len, d_out, n, st, trunc250));
     return P252_OK;
+}
+
+int p252_hash_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
+                           size_t out_len, void* d_out, size_t n, void* hip_stream) {
+    return hash_batch_device_impl(ctx, tag, d_in, in_len, out_len, d_out, n, hip_stream, false);
+}
+
+int p252_hash_batch_truncated_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_in, size_t in_len,
+                                     size_t out_len, void* d_out_raw, size_t n, void* hip_stream) {
+    return hash_batch_device_impl(ctx, tag, d_in, in_len, out_len, d_out_raw, n, hip_stream, true);
 }
 
 static size_t levels_len(size_t n_leaves, size_t arity) {
@@ -227,11 +354,10 @@ int p252host::merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t t
     const char* cur = static_cast<const char*>(d_leaves);
     size_t cur_n = n_leaves;
     char* lv = static_cast<char*>(d_levels);
-    if (!d_levels) {  // ping-pong in context-owned scratch
+    p252_ctx::LevelSet* set = nullptr;
+    if (!d_levels && n_leaves > 1) {  // ping-pong in context-owned scratch: the pair of THIS stream (ctx.hpp)
         const size_t l1 = (n_leaves + arity - 1) / arity, l2 = (l1 + arity - 1) / arity;
-        int rc = ensure(ctx, &ctx->d_lvl[0], &ctx->d_lvl_cap[0], l1 * 32);
-        if (rc) return rc;
-        rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], l2 * 32);
+        int rc = level_set(ctx, st, l1 * 32, l2 * 32, &set);
         if (rc) return rc;
     }
     // A build with wide levels (more nodes than the chip has lanes at one wave per SIMD: 65,536) keeps every SIMD
@@ -247,7 +373,7 @@ int p252host::merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t t
     int parity = 0;
     while (cur_n > 1) {  // a single leaf is its own root: an arity^k-leaf tree costs exactly k levels
         const size_t next_n = (cur_n + arity - 1) / arity;
-        char* next = d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]);
+        char* next = d_levels ? lv : static_cast<char*>(set->buf[parity]);
         HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, arity, pad));
         cur = next;
         cur_n = next_n;
@@ -255,7 +381,7 @@ int p252host::merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t t
         parity ^= 1;
     }
     HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
-    return P252_OK;
+    return set ? level_set_done(ctx, set) : P252_OK;
 }
 }  // extern "C++"
 
@@ -285,10 +411,9 @@ static int forest_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], c
         HIP_TRY(ctx, hipMemcpyAsync(d_roots, d_leaves, cur_n * 32, hipMemcpyDeviceToDevice, st));
         return P252_OK;
     }
-    if (!d_levels) {  // ping-pong in context-owned scratch (the last level goes straight to d_roots)
-        int rc = ensure(ctx, &ctx->d_lvl[0], &ctx->d_lvl_cap[0], cur_n / arity * 32);
-        if (rc) return rc;
-        rc = ensure(ctx, &ctx->d_lvl[1], &ctx->d_lvl_cap[1], cur_n / arity / arity * 32 + 32);
+    p252_ctx::LevelSet* set = nullptr;
+    if (!d_levels) {  // ping-pong in context-owned scratch, this stream's pair (the last level goes straight to d_roots)
+        int rc = level_set(ctx, st, cur_n / arity * 32, cur_n / arity / arity * 32 + 32, &set);
         if (rc) return rc;
     }
     const TagArg t = tag_arg(tag);
@@ -299,7 +424,7 @@ static int forest_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], c
     int parity = 0;
     while (cur_n > n_trees) {
         const size_t next_n = cur_n / arity;
-        char* next = next_n == n_trees ? static_cast<char*>(d_roots) : (d_levels ? lv : static_cast<char*>(ctx->d_lvl[parity]));
+        char* next = next_n == n_trees ? static_cast<char*>(d_roots) : (d_levels ? lv : static_cast<char*>(set->buf[parity]));
         HIP_TRY(ctx, launch_merkle4(ctx->d_tab, t, cur, cur_n, next, next_n, st, arity, pad));
         if (d_levels) {
             if (next_n == n_trees) HIP_TRY(ctx, hipMemcpyAsync(lv, d_roots, next_n * 32, hipMemcpyDeviceToDevice, st));  // levels hold the roots too
@@ -309,7 +434,7 @@ static int forest_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], c
         cur_n = next_n;
         parity ^= 1;
     }
-    return P252_OK;
+    return set ? level_set_done(ctx, set) : P252_OK;
 }
 
 int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
@@ -549,16 +674,16 @@ static size_t staging_chunk_items(size_t bytes_per_item) {
 // n sponge hashes through the staging lanes.  d_resident_out != NULL: the outputs stay on the device (item i at
 // d_resident_out + i * out_len * 32) — the first level of a tree built from host leaves; `out` is then unused.
 static int hash_batch_staged(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
-                             uint64_t* out, size_t n, size_t chunk, char* d_resident_out = nullptr) {
+                             uint64_t* out, size_t n, size_t chunk, char* d_resident_out = nullptr, bool trunc250 = false) {
     const TagArg targ = tag_arg(tag);
     const bool single = in_len == 4 && out_len == 1, pair = in_len == 2 && out_len == 1;
     std::vector<HostSpan> ins = {{reinterpret_cast<const char*>(in), nullptr, in_len * 32}}, outs;
     if (!d_resident_out) outs.push_back({nullptr, reinterpret_cast<char*>(out), out_len * 32});
     return staged_run(ctx, n, chunk, ins, outs, [&](const void* const* d_in, void* const* d_out, size_t off, size_t cnt, hipStream_t st) {
         void* d_dst = d_resident_out ? static_cast<void*>(d_resident_out + off * out_len * 32) : d_out[0];
-        if (single) return launch_merkle4(ctx->d_tab, targ, d_in[0], 4 * cnt, d_dst, cnt, st);
-        if (pair) return launch_merkle4(ctx->d_tab, targ, d_in[0], 2 * cnt, d_dst, cnt, st, 2);
-        return launch_sponge(ctx->d_tab, targ, d_in[0], (unsigned)in_len, (unsigned)out_len, d_dst, cnt, st);
+        if (single) return launch_merkle4(ctx->d_tab, targ, d_in[0], 4 * cnt, d_dst, cnt, st, 4, 0, trunc250);
+        if (pair) return launch_merkle4(ctx->d_tab, targ, d_in[0], 2 * cnt, d_dst, cnt, st, 2, 0, trunc250);
+        return launch_sponge(ctx->d_tab, targ, d_in[0], (unsigned)in_len, (unsigned)out_len, d_dst, cnt, st, trunc250);
     });
 }
 }  // extern "C++"
@@ -590,8 +715,8 @@ int p252_permute_batch(p252_ctx* ctx, const uint64_t* states, uint64_t* out, siz
 }
 
 
-int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
-                    uint64_t* out, size_t n) {
+static int hash_batch_host_impl(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
+                                uint64_t* out, size_t n, bool trunc250) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (in_len == 0 || out_len == 0)
         return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "hash: in_len and out_len must be > 0");
@@ -612,13 +737,13 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
         rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpy(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice));
-        rc = p252_hash_batch_device(ctx, tag, ctx->d_in, in_len, out_len, ctx->d_out, n, nullptr);
+        rc = hash_batch_device_impl(ctx, tag, ctx->d_in, in_len, out_len, ctx->d_out, n, nullptr, trunc250);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost));
         return P252_OK;
     }
     // caller memory that is not page-locked on BOTH sides goes through the library's own staging lanes
-    if (!is_pinned(in) || !is_pinned(out)) return hash_batch_staged(ctx, tag, in, in_len, out_len, out, n, chunk);
+    if (!is_pinned(in) || !is_pinned(out)) return hash_batch_staged(ctx, tag, in, in_len, out_len, out, n, chunk, nullptr, trunc250);
     // page-locked on both sides (p252_host_alloc / p252_host_register): zero-copy DMA, chunks round-robin over 3
     // streams so that the H2D copy of chunk c+1, the kernel of chunk c and the D2H copy of chunk c-1 overlap
     int rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
@@ -639,7 +764,7 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
         char* d_out = static_cast<char*>(ctx->d_out) + off * out_len * 32;
         hipError_t e = hipMemcpyAsync(d_in, h_in, cnt * in_len * 32, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
-            int r2 = p252_hash_batch_device(ctx, tag, d_in, in_len, out_len, d_out, cnt, st);
+            int r2 = hash_batch_device_impl(ctx, tag, d_in, in_len, out_len, d_out, cnt, st, trunc250);
             if (r2) { status = r2; err = ctx->err; break; }
             e = hipMemcpyAsync(h_out, d_out, cnt * out_len * 32, hipMemcpyDeviceToHost, st);
         }
@@ -651,6 +776,16 @@ int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, si
     }
     if (status != P252_OK) return fail(ctx, status, err);
     return P252_OK;
+}
+
+int p252_hash_batch(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
+                    uint64_t* out, size_t n) {
+    return hash_batch_host_impl(ctx, tag, in, in_len, out_len, out, n, false);
+}
+
+int p252_hash_batch_truncated(p252_ctx* ctx, const uint64_t tag[4], const uint64_t* in, size_t in_len, size_t out_len,
+                              uint64_t* out_raw, size_t n) {
+    return hash_batch_host_impl(ctx, tag, in, in_len, out_len, out_raw, n, true);
 }
 
 static int merkle_tree_host(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], const uint64_t* leaves, size_t n_leaves,
@@ -908,13 +1043,14 @@ static int openings_device(p252_ctx* ctx, unsigned arity, const void* d_leaves, 
                            void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (k == 0) return P252_OK;
-    if (n_leaves == 0 || n_leaves > 0xffffffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: n_leaves must be in 1 .. 2^32 - 1 (positions are uint32)");
+    const std::string who = arity == 4 ? "merkle4_openings" : "merkle2_openings";
+    if (n_leaves == 0 || n_leaves > 0xffffffffu) return fail(ctx, P252_ERR_INVALID_ARGUMENT, who + ": n_leaves must be in 1 .. 2^32 - 1 (positions are uint32)");
     const size_t depth = arity == 4 ? p252_merkle4_depth(n_leaves) : p252_merkle2_depth(n_leaves);
     if (!d_leaves || !d_indices || !d_leaves_out || (depth && (!d_levels || !d_siblings || !d_positions)))
-        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: NULL buffer");
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, who + ": NULL buffer");
     if (misaligned(d_leaves) || misaligned(d_levels) || misaligned(d_leaves_out) || misaligned(d_siblings)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
     if ((reinterpret_cast<uintptr_t>(d_indices) & 3u) || (reinterpret_cast<uintptr_t>(d_n_bad) & 3u))
-        return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle4_openings: indices / counter must be 4-byte aligned");
+        return fail(ctx, P252_ERR_INVALID_ARGUMENT, who + ": indices / counter must be 4-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (d_n_bad) HIP_TRY(ctx, hipMemsetAsync(d_n_bad, 0, 4, st));
@@ -1045,8 +1181,9 @@ int p252_decrypt_batch_device(p252_ctx* ctx, int variant, const uint64_t tag[4],
     return crypt_device(ctx, variant, true, tag, d_ciphers, d_secrets, d_nonces, len, d_messages, d_ok, n, hip_stream);
 }
 
-static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t tag[4], const uint64_t* in, const uint64_t* secrets,
-                      const uint64_t* nonces, size_t len, uint64_t* out, uint8_t* ok, size_t n) {
+static int crypt_host_run(p252_ctx* ctx, int variant, bool decrypt, const uint64_t tag[4], const uint64_t* in, const uint64_t* secrets,
+                          const uint64_t* nonces, size_t len, uint64_t* out, uint8_t* ok, size_t n, size_t* used_in, size_t* used_out,
+                          bool* used_lanes) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     if (!crypt_variant_ok(variant)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "encrypt/decrypt: unknown variant");
     if (len == 0) return fail(ctx, P252_ERR_INVALID_IO_PATTERN, "encrypt/decrypt: empty message");
@@ -1070,6 +1207,7 @@ static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t t
                                          {reinterpret_cast<const char*>(nonces), nullptr, 32}};
             std::vector<HostSpan> outs = {{nullptr, reinterpret_cast<char*>(out), out_stride}};
             if (decrypt) outs.push_back({nullptr, reinterpret_cast<char*>(ok), 1});
+            *used_lanes = true;
             return staged_run(ctx, n, chunk, ins, outs,
                               [&](const void* const* d_in, void* const* d_out, size_t, size_t cnt, hipStream_t st) {
                                   return launch_crypt(decrypt, ctx->d_tab, targ, d_in[0], d_in[1], d_in[2], (unsigned)len, d_out[0],
@@ -1085,6 +1223,8 @@ static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t t
     if (rc) return rc;
     char* di = static_cast<char*>(ctx->d_in);
     char* dout = static_cast<char*>(ctx->d_out);
+    *used_in = in_b + sec_b + non_b;
+    *used_out = out_b + ok_b;
     HIP_TRY(ctx, hipMemcpy(di, in, in_b, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(di + in_b, secrets, sec_b, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(di + in_b + sec_b, nonces, non_b, hipMemcpyHostToDevice));
@@ -1093,6 +1233,27 @@ static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t t
     HIP_TRY(ctx, hipMemcpy(out, dout, out_b, hipMemcpyDeviceToHost));
     if (decrypt) HIP_TRY(ctx, hipMemcpy(ok, dout + out_b, n, hipMemcpyDeviceToHost));
     return P252_OK;
+}
+
+// the host-buffer encrypt / decrypt: whatever the call copied into library-owned memory — shared secrets, nonces, plaintexts
+// and ciphertexts in the context's device scratch or in the staging lanes (page-locked host + device chunks) — is cleared
+// before it returns, on success and on failure (the reference: zeroize, Cargo.toml:14; dusk-safe zeroizes a finished sponge)
+static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t tag[4], const uint64_t* in, const uint64_t* secrets,
+                      const uint64_t* nonces, size_t len, uint64_t* out, uint8_t* ok, size_t n) {
+    size_t used_in = 0, used_out = 0;
+    bool used_lanes = false;
+    const int rc = crypt_host_run(ctx, variant, decrypt, tag, in, secrets, nonces, len, out, ok, n, &used_in, &used_out, &used_lanes);
+    if (ctx && (used_in || used_out || used_lanes)) {
+        const std::string msg = ctx->err;
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = wipe_span(ctx->d_in, used_in);
+        if (e == hipSuccess) e = wipe_span(ctx->d_out, used_out);
+        if (e == hipSuccess && used_lanes) e = wipe_lanes(ctx);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess && rc == P252_OK) return fail(ctx, P252_ERR_HIP, std::string("encrypt/decrypt: wiping the scratch failed: ") + hipGetErrorString(e));
+        ctx->err = msg;
+    }
+    return rc;
 }
 
 int p252_encrypt_batch(p252_ctx* ctx, int variant, const uint64_t tag[4], const uint64_t* messages, const uint64_t* secrets,

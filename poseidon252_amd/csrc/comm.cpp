@@ -37,6 +37,13 @@ struct p252_comm {
     void* d_sub = nullptr;    // this rank's subtree root (32 B)
     void* d_roots = nullptr;  // world x 32 B: the gathered roots, in rank order
     void* d_top = nullptr;    // 32 B: the root over the gathered roots (when the caller passes no output pointer)
+    void* d_tab_in = nullptr;  // creation only: where the broadcast constant table lands before it is validated (freed afterwards)
+    // d_sub / d_roots / d_top are ONE set per communicator and the sharded builds are asynchronous on a caller-chosen stream: a
+    // build on another stream than the previous one first waits on the event recorded behind that one (collectives of one
+    // communicator are ordered anyway — every rank must issue them in the same order), so two builds never share the buffers
+    hipEvent_t done = nullptr;
+    hipStream_t last_st = nullptr;
+    bool used = false;
     // communicators of one p252_comm_create_all share this list (rank order): collectives issued for all of them by one
     // host thread go inside one ncclGroupStart / ncclGroupEnd
     std::shared_ptr<std::vector<p252_comm*>> clique;
@@ -52,12 +59,29 @@ struct p252_comm {
 
 namespace {
 
+// everything a communicator allocates, BEFORE the first collective (ncclCommInitRank included): a rank that cannot allocate
+// fails before its peers are blocked in a collective it would then never enter
 int alloc_buffers(p252_comm* c) {
     p252_ctx* ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMalloc(&c->d_sub, 32));
     HIP_TRY(ctx, hipMalloc(&c->d_roots, (size_t)c->world * 32));
     HIP_TRY(ctx, hipMalloc(&c->d_top, 32));
+    HIP_TRY(ctx, hipMalloc(&c->d_tab_in, host_tables().size() * sizeof(int32_t)));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    return P252_OK;
+}
+
+// the buffers' previous user, if it ran on another stream, is waited for on the device; the host never blocks
+int comm_enter(p252_comm* c, hipStream_t st) {
+    if (c->used && c->last_st != st) HIP_TRY(c->ctx, hipStreamWaitEvent(st, c->done, 0));
+    return P252_OK;
+}
+
+int comm_leave(p252_comm* c, hipStream_t st) {
+    c->used = true;
+    c->last_st = st;
+    HIP_TRY(c->ctx, hipEventRecord(c->done, st));
     return P252_OK;
 }
 
@@ -68,6 +92,8 @@ void free_comm(p252_comm* c, bool abort) {
     if (c->d_sub) (void)hipFree(c->d_sub);
     if (c->d_roots) (void)hipFree(c->d_roots);
     if (c->d_top) (void)hipFree(c->d_top);
+    if (c->d_tab_in) (void)hipFree(c->d_tab_in);
+    if (c->done) (void)hipEventDestroy(c->done);
     if (c->ctx && c->ctx->comm == c) c->ctx->comm = nullptr;
     if (c->clique)
         for (auto& p : *c->clique)
@@ -83,12 +109,8 @@ int broadcast_and_validate(const std::vector<p252_comm*>& comms, int root) {
     const size_t bytes = ref.size() * sizeof(int32_t);
     std::vector<void*> scratch(comms.size(), nullptr);
     int rc = P252_OK;
-    for (size_t t = 0; t < comms.size() && rc == P252_OK; ++t) {
-        p252_ctx* ctx = comms[t]->ctx;
-        if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&scratch[t], bytes) != hipSuccess)
-            rc = fail(ctx, P252_ERR_HIP, "comm: scratch allocation for the constant broadcast failed");
-    }
-    if (rc == P252_OK) {
+    for (size_t t = 0; t < comms.size(); ++t) scratch[t] = comms[t]->d_tab_in;  // allocated with the communicator, before any collective
+    {
         ncclResult_t r = ncclGroupStart();
         for (size_t t = 0; t < comms.size() && r == ncclSuccess; ++t) {
             p252_ctx* ctx = comms[t]->ctx;
@@ -115,6 +137,7 @@ int broadcast_and_validate(const std::vector<p252_comm*>& comms, int root) {
         if (scratch[t]) {
             (void)hipSetDevice(comms[t]->ctx->device);
             (void)hipFree(scratch[t]);
+            comms[t]->d_tab_in = nullptr;
         }
     if (rc != P252_OK && comms[0]->ctx->err.empty()) comms[0]->ctx->err = "comm: constant broadcast failed on another rank";
     return rc;
@@ -145,6 +168,12 @@ static std::vector<p252_comm*> clique_of(p252_ctx* const* ctxs, size_t n_ctx) {
     return v;
 }
 
+// why the last lazy communicator creation fell back to the host gather (diagnostics only; P252_OK was returned)
+static std::string& lazy_comm_error() {
+    static std::string e;
+    return e;
+}
+
 static bool distinct_devices(p252_ctx* const* ctxs, size_t n_ctx) {
     // (test-only: tests/test_comm_mock_ranks.py links the library against a mock RCCL that accepts several ranks on one device, to
     // run the multi-rank logic on a one-GPU box; real RCCL refuses such a communicator itself)
@@ -164,16 +193,11 @@ static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm
         if (ctxs[t]->comm) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "comm_create_all: context " + std::to_string(t) + " already belongs to a communicator");
     if (!distinct_devices(ctxs, n_ctx))
         return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "comm_create_all: RCCL needs one device per rank; two of the contexts are bound to the same device");
-    std::vector<int> devs(n_ctx);
-    for (size_t t = 0; t < n_ctx; ++t) devs[t] = ctxs[t]->device;
-    std::vector<ncclComm_t> nc(n_ctx, nullptr);
-    NCCL_TRY(ctxs[0], ncclCommInitAll(nc.data(), (int)n_ctx, devs.data()));
     auto clique = std::make_shared<std::vector<p252_comm*>>(n_ctx, nullptr);
     out.assign(n_ctx, nullptr);
     int rc = P252_OK;
-    for (size_t t = 0; t < n_ctx; ++t) {
+    for (size_t t = 0; t < n_ctx; ++t) {  // the objects and every device allocation first, the collectives after
         p252_comm* c = new p252_comm();
-        c->nccl = nc[t];
         c->ctx = ctxs[t];
         c->rank = (int)t;
         c->world = (int)n_ctx;
@@ -183,6 +207,15 @@ static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm
         out[t] = c;
         ctxs[t]->comm = c;
         if (rc == P252_OK) rc = alloc_buffers(c);
+        if (rc != P252_OK && t != 0 && ctxs[0]->err.empty()) ctxs[0]->err = "context " + std::to_string(t) + ": " + ctxs[t]->err;
+    }
+    if (rc == P252_OK) {
+        std::vector<int> devs(n_ctx);
+        for (size_t t = 0; t < n_ctx; ++t) devs[t] = ctxs[t]->device;
+        std::vector<ncclComm_t> nc(n_ctx, nullptr);
+        const ncclResult_t r = ncclCommInitAll(nc.data(), (int)n_ctx, devs.data());
+        if (r != ncclSuccess) rc = fail(ctxs[0], P252_ERR_COMM, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) out[t]->nccl = nc[t];
     }
     if (rc == P252_OK) rc = broadcast_and_validate(out, 0);
     if (rc != P252_OK) {
@@ -204,14 +237,18 @@ static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm
 static int tree_clique(const std::vector<p252_comm*>& comms, const uint64_t tag[4], const void* const* d_leaves, size_t leaves_per_ctx,
                        void* const* d_root_out, void* const* hip_streams) {
     const size_t n = comms.size();
+    auto stream_of = [&](size_t t) { return (hipStream_t)(hip_streams ? hip_streams[t] : nullptr); };
     int rc = P252_OK;
-    for (size_t t = 0; t < n && rc == P252_OK; ++t)
-        rc = merkle_tree_device(comms[t]->ctx, 4, tag, d_leaves[t], leaves_per_ctx, comms[t]->d_sub, nullptr, hip_streams ? hip_streams[t] : nullptr);
-    if (rc == P252_OK) {
+    for (size_t t = 0; t < n && rc == P252_OK; ++t) {
+        (void)hipSetDevice(comms[t]->ctx->device);
+        rc = comm_enter(comms[t], stream_of(t));
+        if (rc == P252_OK) rc = merkle_tree_device(comms[t]->ctx, 4, tag, d_leaves[t], leaves_per_ctx, comms[t]->d_sub, nullptr, hip_streams ? hip_streams[t] : nullptr);
+    }
+    if (rc == P252_OK) {  // (one host thread drives every rank: a failure above means NO rank has entered the collective yet)
         ncclResult_t r = ncclGroupStart();
         for (size_t t = 0; t < n && r == ncclSuccess; ++t) {
             (void)hipSetDevice(comms[t]->ctx->device);
-            r = ncclAllGather(comms[t]->d_sub, comms[t]->d_roots, 32, ncclUint8, comms[t]->nccl, (hipStream_t)(hip_streams ? hip_streams[t] : nullptr));
+            r = ncclAllGather(comms[t]->d_sub, comms[t]->d_roots, 32, ncclUint8, comms[t]->nccl, stream_of(t));
         }
         const ncclResult_t r2 = ncclGroupEnd();
         if (r == ncclSuccess) r = r2;
@@ -220,6 +257,7 @@ static int tree_clique(const std::vector<p252_comm*>& comms, const uint64_t tag[
     for (size_t t = 0; t < n && rc == P252_OK; ++t) {
         void* dst = (d_root_out && d_root_out[t]) ? d_root_out[t] : comms[t]->d_top;
         rc = merkle_tree_device(comms[t]->ctx, 4, tag, comms[t]->d_roots, n, dst, nullptr, hip_streams ? hip_streams[t] : nullptr);
+        if (rc == P252_OK) rc = comm_leave(comms[t], stream_of(t));
     }
     if (rc != P252_OK && comms[0]->ctx->err.empty()) comms[0]->ctx->err = "sharded tree failed on another context";
     return rc;
@@ -235,13 +273,46 @@ int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t t
         const char* e = std::getenv("P252_MULTI_HOST_GATHER");
         return e && e[0] == '1';
     }();
+    if (n_ctx == 1 && !(ctxs[0]->comm && !ctxs[0]->comm->owned_by_ctx)) {
+        // one context: nothing to exchange — no communicator is created (and the context is not tied to a hidden one);
+        // *used_rccl = true only says "the root is where d_root_out asked for it"
+        if (d_root_out && d_root_out[0]) {
+            int rc = merkle_tree_device(ctxs[0], 4, tag, d_leaves[0], leaves_per_ctx, d_root_out[0], nullptr, hip_streams ? hip_streams[0] : nullptr);
+            if (rc) return rc;
+        }
+        *used_rccl = true;
+        return P252_OK;
+    }
     std::vector<p252_comm*> comms = clique_of(ctxs, n_ctx);
     if (comms.empty()) {
         if (host_gather || !distinct_devices(ctxs, n_ctx)) return P252_OK;
         static std::mutex mu;  // one lazy creation at a time
         std::lock_guard<std::mutex> lk(mu);
+        // ABI 5 accepted ANY array of contexts.  A context that already sits in a communicator over ANOTHER array (other count,
+        // order or subset — ctxs[:4] after ctxs[:8]) must not make the call fail:
+        //  * a communicator the CALLER made (p252_comm_create_rank / _create_all) is the caller's to keep: the roots are gathered
+        //    through the host instead (P252_OK with *used_rccl = false);
+        //  * communicators this entry point made itself (owned by their contexts) are torn down — every member of each such
+        //    clique, RCCL communicators go collectively — and one over the new array is created.
+        for (size_t t = 0; t < n_ctx; ++t)
+            if (ctxs[t]->comm && !ctxs[t]->comm->owned_by_ctx) return P252_OK;
+        for (size_t t = 0; t < n_ctx; ++t)
+            if (ctxs[t]->comm) {
+                const auto clique = ctxs[t]->comm->clique;  // (keeps the list alive while its members go)
+                const std::vector<p252_comm*> members = clique ? *clique : std::vector<p252_comm*>{ctxs[t]->comm};
+                for (p252_comm* m : members)
+                    if (m && m->ctx) {
+                        (void)hipSetDevice(m->ctx->device);
+                        (void)hipDeviceSynchronize();  // nothing of the old clique may still be queued
+                    }
+                for (p252_comm* m : members) free_comm(m, false);
+            }
         int rc = create_all(ctxs, n_ctx, comms, /*owned=*/true);
-        if (rc) return rc;
+        if (rc) {  // no communicator to be had (ncclCommInitAll refused): the host gather still exists — use it, say why
+            lazy_comm_error() = ctxs[0]->err;
+            ctxs[0]->err.clear();
+            return P252_OK;
+        }
     }
     *used_rccl = true;
     return tree_clique(comms, tag, d_leaves, leaves_per_ctx, d_root_out, hip_streams);
@@ -265,19 +336,24 @@ int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, i
     if (!id || len != P252_COMM_ID_BYTES) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: id must be the P252_COMM_ID_BYTES bytes of p252_comm_unique_id");
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: need 0 <= rank < world");
     if (ctx->comm) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: the context already belongs to a communicator");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ncclUniqueId uid;
-    std::memcpy(uid.internal, id, P252_COMM_ID_BYTES);
-    ncclComm_t nc = nullptr;
-    NCCL_TRY(ctx, ncclCommInitRank(&nc, world, uid, rank));
+    // every allocation BEFORE the first collective: a rank that cannot allocate returns here, while its peers have not yet entered
+    // anything they would wait in for it; from ncclCommInitRank on, creation is collective — a failure on one rank (reported on
+    // that rank) aborts its communicator, and the job must treat it as the failure of all (header: "collective")
     p252_comm* c = new p252_comm();
-    c->nccl = nc;
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
-    ctx->comm = c;
     int rc = alloc_buffers(c);
-    if (rc == P252_OK) rc = broadcast_and_validate(std::vector<p252_comm*>{c}, 0);
+    if (rc == P252_OK) {
+        ncclUniqueId uid;
+        std::memcpy(uid.internal, id, P252_COMM_ID_BYTES);
+        const ncclResult_t r = ncclCommInitRank(&c->nccl, world, uid, rank);
+        if (r != ncclSuccess) rc = fail(ctx, P252_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    }
+    if (rc == P252_OK) {
+        ctx->comm = c;
+        rc = broadcast_and_validate(std::vector<p252_comm*>{c}, 0);
+    }
     if (rc != P252_OK) {
         const std::string msg = ctx->err;
         free_comm(c, true);
@@ -310,14 +386,28 @@ int p252_merkle4_tree_sharded_device(p252_comm* comm, const uint64_t tag[4], con
     if (!tag || !d_leaves || !d_root) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree_sharded: NULL buffer");
     if (!power_of_4(n_leaves_local))
         return fail(ctx, P252_ERR_INVALID_ARGUMENT, "merkle_tree_sharded: every rank must own a complete subtree (4^k leaves)");
-    // the rank's subtree (zero communication) ...
-    int rc = merkle_tree_device(ctx, 4, tag, d_leaves, n_leaves_local, comm->d_sub, nullptr, hip_stream);
-    if (rc) return rc;
-    // ... the path's only exchange step, on the same stream: world x 32 bytes to every rank ...
+    hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    NCCL_TRY(ctx, ncclAllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, (hipStream_t)hip_stream));
+    int rc = comm_enter(comm, st);
+    // the rank's subtree (zero communication) ...
+    if (rc == P252_OK) rc = merkle_tree_device(ctx, 4, tag, d_leaves, n_leaves_local, comm->d_sub, nullptr, hip_stream);
+    if (rc) {
+        // A LOCAL failure (allocation of the level scratch) must not leave the peers blocked on the stream in a collective this
+        // rank never enters: the rank still contributes — an all-ones root, which is no BlsScalar (>= p) — and returns
+        // its error; the job treats one rank's failure as the build's, as with any collective.
+        const std::string msg = ctx->err;
+        (void)hipMemsetAsync(comm->d_sub, 0xff, 32, st);
+        (void)ncclAllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st);
+        (void)comm_leave(comm, st);
+        ctx->err = msg;
+        return rc;
+    }
+    // ... the path's only exchange step, on the same stream: world x 32 bytes to every rank ...
+    NCCL_TRY(ctx, ncclAllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st));
     // ... and the top levels, on every rank (a single rank's "tree over one root" is a copy)
-    return merkle_tree_device(ctx, 4, tag, comm->d_roots, (size_t)comm->world, d_root, nullptr, hip_stream);
+    rc = merkle_tree_device(ctx, 4, tag, comm->d_roots, (size_t)comm->world, d_root, nullptr, hip_stream);
+    const int rc2 = comm_leave(comm, st);
+    return rc ? rc : rc2;
 }
 
 int p252_merkle4_tree_multi_device_resident(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves,

@@ -20,8 +20,20 @@ struct p252_ctx {
     size_t d_in_cap = 0;
     void* d_out = nullptr;
     size_t d_out_cap = 0;
-    void* d_lvl[2] = {nullptr, nullptr};
-    size_t d_lvl_cap[2] = {0, 0};
+    // Root-only tree / forest builds ping-pong two level buffers.  The `_device` builders are asynchronous on a caller-chosen
+    // stream, so ONE pair per context would be shared by builds queued on different streams (round 4: silent wrong roots).  Each
+    // caller stream therefore owns a pair (up to MAX_LEVEL_SETS); a further stream takes over the least recently used pair after
+    // waiting on the event recorded behind that pair's last build — builds on different streams overlap, none ever shares scratch.
+    struct LevelSet {
+        hipStream_t st = nullptr;
+        void* buf[2] = {nullptr, nullptr};
+        size_t cap[2] = {0, 0};
+        hipEvent_t done = nullptr;  // recorded on `st` behind the last launch that touches buf[]
+        uint64_t stamp = 0;         // use counter value of the last build (least recently used = smallest)
+    };
+    static constexpr size_t MAX_LEVEL_SETS = 4;
+    std::vector<LevelSet> lvl;
+    uint64_t lvl_clock = 0;
     hipStream_t streams[3] = {nullptr, nullptr, nullptr};  // host-buffer pipeline over caller-pinned memory (created on first use)
     // host-buffer pipeline over PAGEABLE caller memory: library-owned page-locked staging, one lane per worker thread
     // (stream + pinned in/out chunk + device in/out chunk), created on first use and kept
@@ -53,6 +65,9 @@ struct p252_ctx {
 namespace p252host {
 int fail(p252_ctx* ctx, int code, const std::string& msg);
 int ensure(p252_ctx* ctx, void** buf, size_t* cap, size_t need);
+// the level-scratch pair of a root-only build on `st` (at least need0 / need1 bytes); level_set_done() after the build's last launch
+int level_set(p252_ctx* ctx, hipStream_t st, size_t need0, size_t need1, p252_ctx::LevelSet** out);
+int level_set_done(p252_ctx* ctx, p252_ctx::LevelSet* set);
 const std::vector<int32_t>& host_tables();
 bool power_of_4(size_t v);
 int check_ctxs(p252_ctx* const* ctxs, size_t n_ctx);

@@ -20,15 +20,16 @@ struct TagArg {
 
 hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t n, hipStream_t st);
 // pad_lanes > n: the n nodes are computed redundantly by pad_lanes lanes (k_merkle4_pad: narrow levels of a large tree)
+// trunc250: the output stage stores finalize_truncated's raw limbs (canonical value & (2^250 - 1), hash.rs:164-183) instead of BlsScalars
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
-                          void* out, size_t n, hipStream_t st, unsigned arity = 4, size_t pad_lanes = 0);
+                          void* out, size_t n, hipStream_t st, unsigned arity = 4, size_t pad_lanes = 0, bool trunc250 = false);
 // incremental tree update: index[k] = leaf positions (u32); one level: node = index[i] >> shift, re-hashed from `children`
 // (index[i] >= n_dst: skipped, *n_bad incremented when n_bad != nullptr)
 hipError_t launch_scatter_scalars(const void* index, const void* values, void* dst, size_t k, size_t n_dst, void* n_bad, hipStream_t st);
 hipError_t launch_merkle4_update(const int32_t* tab, const TagArg& tag, const void* index, unsigned shift, const void* children,
                                  size_t n_children, void* out, size_t k, hipStream_t st);
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
-                         unsigned out_len, void* out, size_t n, hipStream_t st);
+                         unsigned out_len, void* out, size_t n, hipStream_t st, bool trunc250 = false);
 
 // prog: device array of n_calls sponge-call words (kind << 29 | len), see k_crypt
 hipError_t launch_crypt(bool decrypt, const int32_t* tab, const TagArg& tag, const void* in, const void* secrets,

@@ -70,6 +70,30 @@ __device__ __forceinline__ void store_scalar(Scalar32* __restrict__ p, const E29
     *(reinterpret_cast<uint4*>(p) + 1) = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// Hash::finalize_truncated's output (hash.rs:164-183) from the kernel that already holds the value: the canonical
+// value (Montgomery form dropped: redc(V * 2^5) = V * 2^5 / 2^261 = V / 2^256) & (2^250 - 1), stored as the raw limbs
+// JubJubScalar::from_raw receives.  e is a tight residue (|V| < 2p < 2^256), so the reduction lands in [-p, 0]: two conditional
+// subtractions canonicalise.  One product + one reduction per OUTPUT scalar (~110 of a digest's 77,000 instructions) instead of
+// a second launch and a 64 B / scalar round trip through HBM (k_to_canonical<true>, kept for scalars that are already stored).
+__device__ __forceinline__ void store_truncated(Scalar32* __restrict__ p, const E29& e) {
+    const int32_t c32[NL] = {32, 0, 0, 0, 0, 0, 0, 0, 0};
+    A29 t;
+    acc_zero(t);
+    acc_mul(t, e, c32);
+    uint32_t w[8];
+    to_mont4<2>(redc(t), w);
+    w[7] &= 0x03ffffffu;  // TRUNCATION_MASK: keep the low 250 bits
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(reinterpret_cast<uint4*>(p) + 1) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+template <bool TRUNC>
+__device__ __forceinline__ void store_output(Scalar32* __restrict__ p, const E29& e) {
+    if (TRUNC)
+        store_truncated(p, e);
+    else
+        store_scalar(p, e);
+}
+
 // ---- n independent permutations (Safe::permute, scalar.rs:25-27) ----
 // (k_permute, k_sponge and k_crypt keep all five lanes: 205-225 VGPRs = 2 waves per SIMD.  Held at 3 waves they spill
 // 15-19 registers to scratch and gain 1 % on config 4 (same-box A/B, profiles/r02_ab_occupancy.txt) — at the price of
@@ -94,6 +118,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute(const int32_t* __restric
 // k_merkle4_lat for launches of at most one wave per SIMD — a tree's narrow levels, small batches — where occupancy
 // is irrelevant and the unconstrained register allocation's schedule runs a lone wave 3.6 % faster (same-box A/B,
 // profiles/r02_ab_occupancy.txt). ----
+template <bool TRUNC = false>
 __device__ __forceinline__ void merkle4_body(const int32_t* __restrict__ tab, const TagArg& tag,
                                              const Scalar32* __restrict__ children, size_t n_children,
                                              Scalar32* __restrict__ out, size_t n, unsigned arity) {
@@ -113,13 +138,20 @@ __device__ __forceinline__ void merkle4_body(const int32_t* __restrict__ tab, co
             s[1 + k] = e29_zero();
     }
     hades_permute<0x02u, true>(s, tab);  // only lane 1 is squeezed
-    store_scalar(out + idx, s[1]);
+    store_output<TRUNC>(out + idx, s[1]);
 }
 __global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4(const int32_t* __restrict__ tab, TagArg tag,
                                                         const Scalar32* __restrict__ children,
                                                         size_t n_children, Scalar32* __restrict__ out,
                                                         size_t n, unsigned arity) {
     merkle4_body(tab, tag, children, n_children, out, n, arity);
+}
+// Hash::digest_truncated for a batch (hash.rs:203-210): the same kernel with the truncating output stage — ONE launch
+__global__ void __launch_bounds__(P252_BLOCK) P252_WAVES_ATTR k_merkle4_trunc(const int32_t* __restrict__ tab, TagArg tag,
+                                                        const Scalar32* __restrict__ children,
+                                                        size_t n_children, Scalar32* __restrict__ out,
+                                                        size_t n, unsigned arity) {
+    merkle4_body<true>(tab, tag, children, n_children, out, n, arity);
 }
 __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_lat(const int32_t* __restrict__ tab, TagArg tag,
                                                             const Scalar32* __restrict__ children,
@@ -205,11 +237,11 @@ __device__ __forceinline__ E29 load_child_or_zero(const Scalar32* __restrict__ c
     const bool present = k >= 0 && (unsigned)k < arity && c < n_children;
     return present ? load_scalar(children + c) : e29_zero();
 }
-template <int LANES>
-__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __restrict__ tab, TagArg tag,
-                                                             const Scalar32* __restrict__ children,
-                                                             size_t n_children, Scalar32* __restrict__ out,
-                                                             size_t n, unsigned arity, size_t lanes) {
+template <int LANES, bool TRUNC>
+__device__ __forceinline__ void merkle4_coop_body(const int32_t* __restrict__ tab, const TagArg& tag,
+                                                  const Scalar32* __restrict__ children,
+                                                  size_t n_children, Scalar32* __restrict__ out,
+                                                  size_t n, unsigned arity, size_t lanes) {
     const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     if (lane >= lanes) return;  // (lanes is a multiple of LANES — launch_merkle4 rounds it up: whole groups only)
     const size_t idx = (unsigned)(lane / LANES) % (unsigned)n;  // (n <= 16,384 here: no 64-bit division)
@@ -232,7 +264,20 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __re
         CoopLane<4> L = coop_lane<4>(tab, cm);
         hades_permute_coop<4, false>(mine, last, tab, cm, L);
     }
-    if (j == 1) store_scalar(out + idx, mine);  // the digest is element 1 of the permuted state: lane 1's
+    if (j == 1) store_output<TRUNC>(out + idx, mine);  // the digest is element 1 of the permuted state: lane 1's
+}
+template <int LANES>
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop(const int32_t* __restrict__ tab, TagArg tag,
+                                                             const Scalar32* __restrict__ children,
+                                                             size_t n_children, Scalar32* __restrict__ out,
+                                                             size_t n, unsigned arity, size_t lanes) {
+    merkle4_coop_body<LANES, false>(tab, tag, children, n_children, out, n, arity, lanes);
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_merkle4_coop8_trunc(const int32_t* __restrict__ tab, TagArg tag,
+                                                                    const Scalar32* __restrict__ children,
+                                                                    size_t n_children, Scalar32* __restrict__ out,
+                                                                    size_t n, unsigned arity, size_t lanes) {
+    merkle4_coop_body<8, true>(tab, tag, children, n_children, out, n, arity, lanes);
 }
 
 // ---- incremental update of a stored tree: k leaves changed; per level, update i re-hashes the node above
@@ -311,9 +356,10 @@ __global__ void __launch_bounds__(P252_BLOCK) k_permute_coop(const int32_t* __re
 }
 
 // the sponge of k_sponge with the state spread over a group: lane 0 the capacity element, lanes 1..4 the rate
-__global__ void __launch_bounds__(P252_BLOCK) k_sponge_coop(const int32_t* __restrict__ tab, TagArg tag,
-                                                            const Scalar32* __restrict__ in, unsigned in_len,
-                                                            unsigned out_len, Scalar32* __restrict__ out, size_t n) {
+template <bool TRUNC>
+__device__ __forceinline__ void sponge_coop_body(const int32_t* __restrict__ tab, const TagArg& tag,
+                                                 const Scalar32* __restrict__ in, unsigned in_len,
+                                                 unsigned out_len, Scalar32* __restrict__ out, size_t n) {
     const size_t lane = (size_t)blockIdx.x * P252_BLOCK + threadIdx.x;
     const size_t idx = lane / 8;
     if (idx >= n) return;
@@ -337,9 +383,19 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge_coop(const int32_t* __res
             if (rate && e < in_len) add_e(s, load_scalar(my_in + e));  // Safe::add, scalar.rs:33-35
         } else {
             const unsigned o = (it - absorb_blocks) * 4 + slot;
-            if (rate && j < WIDTH && o < out_len) store_scalar(my_out + o, s);
+            if (rate && j < WIDTH && o < out_len) store_output<TRUNC>(my_out + o, s);
         }
     }
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge_coop(const int32_t* __restrict__ tab, TagArg tag,
+                                                            const Scalar32* __restrict__ in, unsigned in_len,
+                                                            unsigned out_len, Scalar32* __restrict__ out, size_t n) {
+    sponge_coop_body<false>(tab, tag, in, in_len, out_len, out, n);
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge_coop_trunc(const int32_t* __restrict__ tab, TagArg tag,
+                                                                  const Scalar32* __restrict__ in, unsigned in_len,
+                                                                  unsigned out_len, Scalar32* __restrict__ out, size_t n) {
+    sponge_coop_body<true>(tab, tag, in, in_len, out_len, out, n);
 }
 
 // the opening of k_merkle4_path on a group: lane 0 the tag, lane 1 + slot the child in that slot of the node
@@ -388,7 +444,7 @@ __global__ void __launch_bounds__(P252_BLOCK) k_merkle4_path_coop(const int32_t*
 // at its first block: the lane fetches its two tail scalars then as well (the same line at the same time: one HBM fetch)
 // and parks them in LDS (64 B per lane, private: no barrier) until its last block.  Every line is touched once.  Taken
 // when in_len is even and the array is 64-byte aligned (kernel-uniform); otherwise block by block as before. ----
-template <bool LINES>
+template <bool LINES, bool TRUNC = false>
 __device__ __forceinline__ void sponge_body(const int32_t* __restrict__ tab, const TagArg& tag, const Scalar32* __restrict__ in,
                                             unsigned in_len, unsigned out_len, Scalar32* __restrict__ out, size_t n) {
     __shared__ uint4 tail[LINES ? 4 : 1][LINES ? P252_BLOCK : 1];  // [half record][lane]: the two tail scalars of a message ending in mid-line
@@ -456,7 +512,7 @@ __device__ __forceinline__ void sponge_body(const int32_t* __restrict__ tab, con
             const unsigned ob = (it - absorb_blocks) * 4;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (ob + k < out_len) store_scalar(my_out + ob + k, s[1 + k]);
+                if (ob + k < out_len) store_output<TRUNC>(my_out + ob + k, s[1 + k]);
         }
     }
 }
@@ -471,6 +527,19 @@ __global__ void __launch_bounds__(P252_BLOCK) k_sponge_lines(const int32_t* __re
                                                              unsigned out_len, Scalar32* __restrict__ out,
                                                              size_t n) {
     sponge_body<true>(tab, tag, in, in_len, out_len, out, n);
+}
+// Hash::finalize_truncated for a batch (hash.rs:164-183): the truncating output stage, every squeezed scalar — ONE launch
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge_trunc(const int32_t* __restrict__ tab, TagArg tag,
+                                                             const Scalar32* __restrict__ in, unsigned in_len,
+                                                             unsigned out_len, Scalar32* __restrict__ out,
+                                                             size_t n) {
+    sponge_body<false, true>(tab, tag, in, in_len, out_len, out, n);
+}
+__global__ void __launch_bounds__(P252_BLOCK) k_sponge_lines_trunc(const int32_t* __restrict__ tab, TagArg tag,
+                                                                   const Scalar32* __restrict__ in, unsigned in_len,
+                                                                   unsigned out_len, Scalar32* __restrict__ out,
+                                                                   size_t n) {
+    sponge_body<true, true>(tab, tag, in, in_len, out_len, out, n);
 }
 
 // ---- batched encryption / decryption (src/encryption.rs:62-95 -> dusk_safe::encrypt / decrypt) ----
@@ -874,8 +943,19 @@ hipError_t launch_permute(const int32_t* tab, const void* in, void* out, size_t 
 }
 
 hipError_t launch_merkle4(const int32_t* tab, const TagArg& tag, const void* children, size_t n_children,
-                          void* out, size_t n, hipStream_t st, unsigned arity, size_t pad_lanes) {
+                          void* out, size_t n, hipStream_t st, unsigned arity, size_t pad_lanes, bool trunc250) {
     if (n == 0) return hipSuccess;
+    if (trunc250) {  // digest_truncated: lane groups for what cannot fill the chip, the 3-waves-per-SIMD build otherwise
+        if (coop8(n)) {
+            const size_t lanes = n * 8;
+            hipLaunchKernelGGL(k_merkle4_coop8_trunc, dim3(grid_for(lanes)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity, lanes);
+        } else {
+            hipLaunchKernelGGL(k_merkle4_trunc, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(children), n_children, static_cast<Scalar32*>(out), n, arity);
+        }
+        return hipGetLastError();
+    }
     if (pad_lanes >= ((size_t)1 << 31)) pad_lanes = 0;  // (the padded kernels index with 32 bits)
     // launches of at most one wave per SIMD with 8 (4) lanes per node: the cooperative low-latency builds
     if (n <= coop_max_nodes() && n * 4 <= (size_t)65536) {
@@ -937,8 +1017,20 @@ hipError_t launch_merkle4_update(const int32_t* tab, const TagArg& tag, const vo
 }
 
 hipError_t launch_sponge(const int32_t* tab, const TagArg& tag, const void* in, unsigned in_len,
-                         unsigned out_len, void* out, size_t n, hipStream_t st) {
+                         unsigned out_len, void* out, size_t n, hipStream_t st, bool trunc250) {
     if (n == 0) return hipSuccess;
+    if (trunc250) {
+        if (coop8(n))
+            hipLaunchKernelGGL(k_sponge_coop_trunc, dim3(grid_for(n * 8)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+        else if (line_fetch() && (in_len & 1u) == 0 && (reinterpret_cast<uintptr_t>(in) & 63u) == 0)
+            hipLaunchKernelGGL(k_sponge_lines_trunc, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+        else
+            hipLaunchKernelGGL(k_sponge_trunc, dim3(grid_for(n)), dim3(P252_BLOCK), 0, st, tab, tag,
+                               static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);
+        return hipGetLastError();
+    }
     if (coop8(n)) {
         hipLaunchKernelGGL(k_sponge_coop, dim3(grid_for(n * 8)), dim3(P252_BLOCK), 0, st, tab, tag,
                            static_cast<const Scalar32*>(in), in_len, out_len, static_cast<Scalar32*>(out), n);

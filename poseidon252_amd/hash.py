@@ -151,7 +151,19 @@ class Context:
         self._check(_lib.lib().p252_permute_batch(self._h, s.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p), s.shape[0]))
         return out
 
-    def hash_batch(self, tag, messages, in_len, out_len, out=None):
+    def wipe(self):
+        """clear every scratch buffer the context owns (p252_wipe: device scratch, level scratch, staging lanes).  The host-buffer
+        encrypt / decrypt calls and close() do this themselves (the reference builds with `zeroize`, Cargo.toml:14)."""
+        self._check(_lib.lib().p252_wipe(self._h))
+
+    def scratch_residue(self):
+        """diagnostics: non-zero bytes in the context's scratch buffers (p252_scratch_residue)"""
+        n = ctypes.c_uint64(0)
+        self._check(_lib.lib().p252_scratch_residue(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def hash_batch(self, tag, messages, in_len, out_len, out=None, truncated=False):
+        """truncated=True: Hash::finalize_truncated's raw limbs (hash.rs:164-183), produced by the digest kernel's output stage"""
         tag = _as_scalars(tag).reshape(4)
         m = _as_scalars(messages)
         if in_len <= 0:
@@ -162,8 +174,8 @@ class Context:
         else:  # caller-provided (e.g. pinned) output buffer
             assert out.dtype == np.uint64 and out.flags.c_contiguous and out.size == m.shape[0] * out_len * 4
             out = out.reshape(m.shape[0], out_len, 4)
-        self._check(_lib.lib().p252_hash_batch(self._h, tag.ctypes.data_as(_u64p), m.ctypes.data_as(_u64p),
-                                                in_len, out_len, out.ctypes.data_as(_u64p), m.shape[0]))
+        fn = _lib.lib().p252_hash_batch_truncated if truncated else _lib.lib().p252_hash_batch
+        self._check(fn(self._h, tag.ctypes.data_as(_u64p), m.ctypes.data_as(_u64p), in_len, out_len, out.ctypes.data_as(_u64p), m.shape[0]))
         return out
 
     def merkle4_tree(self, tag, leaves, want_levels=False):
@@ -204,12 +216,13 @@ class Context:
         assert self._nbytes(d_states) >= n * 160 and self._nbytes(d_out) >= n * 160
         self._check(_lib.lib().p252_permute_batch_device(self._h, d_states.data_ptr(), d_out.data_ptr(), n, self._stream()))
 
-    def hash_batch_device(self, tag, d_in, in_len, out_len, d_out, n):
+    def hash_batch_device(self, tag, d_in, in_len, out_len, d_out, n, truncated=False):
+        """truncated=True: p252_hash_batch_truncated_device — finalize_truncated's raw limbs from the SAME launch (hash.rs:164-183)"""
         tag = _as_scalars(tag).reshape(4)
         assert d_in.is_cuda and d_out.is_cuda and d_in.is_contiguous() and d_out.is_contiguous()
         assert self._nbytes(d_in) >= n * in_len * 32 and self._nbytes(d_out) >= n * out_len * 32
-        self._check(_lib.lib().p252_hash_batch_device(self._h, tag.ctypes.data_as(_u64p), d_in.data_ptr(), in_len, out_len,
-                                                       d_out.data_ptr(), n, self._stream()))
+        fn = _lib.lib().p252_hash_batch_truncated_device if truncated else _lib.lib().p252_hash_batch_device
+        self._check(fn(self._h, tag.ctypes.data_as(_u64p), d_in.data_ptr(), in_len, out_len, d_out.data_ptr(), n, self._stream()))
 
     def merkle4_tree_device(self, tag, d_leaves, n_leaves, d_root, d_levels=None):
         tag = _as_scalars(tag).reshape(4)
@@ -479,16 +492,16 @@ class Hash:
     def update(self, scalars):  # hash.rs:118-120
         self.input.append(_as_scalars(scalars).reshape(-1, 4))
 
-    def finalize(self):  # hash.rs:128-155
+    def finalize(self, truncated=False):  # hash.rs:128-155
         lens = [c.shape[0] for c in self.input]
         check_io_pattern(self.domain, lens, self._output_len)  # raises where the reference panics
         tag = self._tag if self._tag is not None else compute_tag(self.domain, lens, self._output_len)
         msg = np.concatenate(self.input, axis=0)
         ctx = self._ctx or Context.default()
-        return ctx.hash_batch(tag, msg[None], msg.shape[0], self._output_len)[0]
+        return ctx.hash_batch(tag, msg[None], msg.shape[0], self._output_len, truncated=truncated)[0]
 
-    def finalize_truncated(self):  # hash.rs:164-183
-        return truncate250(self.finalize())
+    def finalize_truncated(self):  # hash.rs:164-183 — truncated by the digest kernel's output stage (one launch)
+        return self.finalize(truncated=True)
 
     @classmethod
     def digest(cls, domain, scalars, **kw):  # hash.rs:191-195
@@ -523,20 +536,17 @@ class HashBatch:
             self._ctx = Context.default()
         return self._ctx
 
-    def digest(self, scalars, out=None):
+    def digest(self, scalars, out=None, truncated=False):
         if _is_torch(scalars):
             import torch
             n = scalars.numel() * scalars.element_size() // (self.item_len * 32)
             if out is None:
                 out = torch.empty((n, self.out_len, 4), dtype=torch.int64, device=scalars.device)
-            self.ctx.hash_batch_device(self.tag, scalars, self.item_len, self.out_len, out, n)
+            self.ctx.hash_batch_device(self.tag, scalars, self.item_len, self.out_len, out, n, truncated=truncated)
             return out
-        return self.ctx.hash_batch(self.tag, scalars, self.item_len, self.out_len, out=out)
+        return self.ctx.hash_batch(self.tag, scalars, self.item_len, self.out_len, out=out, truncated=truncated)
 
-    def digest_truncated(self, scalars):
-        """Hash::digest_truncated (hash.rs:203-210) per item; device tensors are truncated on the device"""
-        out = self.digest(scalars)
-        if _is_torch(out):
-            self.ctx.truncate250_device(out, out, out.numel() // 4)
-            return out
-        return truncate250(out)
+    def digest_truncated(self, scalars, out=None):
+        """Hash::digest_truncated (hash.rs:203-210) per item, host or device buffers: ONE kernel launch — the digest kernel's
+        output stage canonicalises, masks to 250 bits and stores the raw limbs JubJubScalar::from_raw receives (SURVEY §8 f2)"""
+        return self.digest(scalars, out=out, truncated=True)

@@ -123,7 +123,7 @@ int main(void) {
             p252_destroy(c2); /* context first: the communicator stays a husk to destroy */
             p252_comm_destroy(cr);
         }
-        /* the multi-device entry point creates its communicator itself (contexts on distinct devices) and keeps it */
+        /* the multi-device entry point: ONE context has nothing to exchange (no communicator is made; ABI 7) */
         {
             const void* dl[1];
             void* dr[1];
@@ -150,7 +150,14 @@ int main(void) {
                     CHECK(p252_merkle4_tree_multi_device(two, 2, tag, dl2, 1024, root3) == P252_OK);
                 }
             }
-            p252_destroy(c3); /* takes the library-made communicator with it */
+            {   /* ... so the context is free to join the caller's communicator afterwards, and the same calls then run through it */
+                p252_comm* own = NULL;
+                CHECK(p252_comm_create_all(&c3, 1, &own) == P252_OK && own != NULL);
+                memset(root3, 0, 32);
+                CHECK(p252_merkle4_tree_multi_device(&c3, 1, tag, dl, 4 * (size_t)N, root3) == P252_OK && memcmp(root3, root, 32) == 0);
+                p252_comm_destroy(own);
+            }
+            p252_destroy(c3);
         }
         /* forest: 1,024 trees of 16 leaves, one launch per level across all trees = level 2 of the big tree above */
         CHECK(p252_merkle4_forest_device(ctx, tag, d_leaves, (size_t)N / 4, 16, d_forest, NULL, NULL) == P252_OK);
@@ -160,6 +167,18 @@ int main(void) {
         memset(out2, 0, 32 * (size_t)N / 4); /* the host-buffer twin: leaves in, roots out */
         CHECK(p252_merkle4_forest(ctx, tag, in, (size_t)N / 4, 16, out2) == P252_OK && memcmp(out2, levels + 4 * (size_t)N, 32 * (size_t)N / 4) == 0);
         CHECK(hipFree(d_leaves) == 0 && hipFree(d_root) == 0 && hipFree(d_forest) == 0);
+    }
+    /* ABI 7: Hash::digest_truncated for the batch in one launch (hash.rs:164-183, 203-210) == the host rule on the full digests;
+     * secret hygiene: the library-owned scratch counts non-zero bytes until it is wiped */
+    {
+        uint64_t residue = 1;
+        CHECK(p252_hash_batch_truncated(ctx, tag, in, 4, 1, out2, N) == P252_OK);
+        CHECK(p252_truncate250(out, st_out, N) == P252_OK && memcmp(out2, st_out, 32 * (size_t)N) == 0);
+        for (size_t i = 0; i < N; ++i) CHECK((out2[4 * i + 3] >> 58) == 0); /* below 2^250 */
+        CHECK(p252_scratch_residue(ctx, &residue) == P252_OK && residue > 0);
+        CHECK(p252_wipe(ctx) == P252_OK && p252_scratch_residue(ctx, &residue) == P252_OK && residue == 0);
+        CHECK(p252_hash_batch(ctx, tag, in, 4, 1, out2, N) == P252_OK && memcmp(out, out2, 32 * (size_t)N) == 0); /* works as before */
+        CHECK(p252_wipe(NULL) == P252_ERR_INVALID_ARGUMENT && p252_scratch_residue(ctx, NULL) == P252_ERR_INVALID_ARGUMENT);
     }
     /* error paths return codes, nothing unwinds */
     CHECK(p252_hash_batch(ctx, tag, in, 0, 1, out, N) == P252_ERR_INVALID_IO_PATTERN && strlen(p252_last_error(ctx)) > 0);

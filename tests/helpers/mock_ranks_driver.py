@@ -88,11 +88,19 @@ for world, per in ((8, 4 ** 5), (4, 4 ** 4), (3, 4 ** 2), (6, 4)):
     C.merkle4_tree_multi_device_resident(ctxs, tag, d, per, d_roots)
     torch.cuda.synchronize()
     assert all(np.array_equal(r.cpu().numpy().view(np.uint64), exp) for r in d_roots)  # the root is resident on EVERY rank
-    try:  # the contexts in another order are not this clique (rank t must be ctxs[t]) and already belong to a communicator
-        multi.merkle4_tree_multi_device(ctxs[::-1], tag, d, per)
-        raise SystemExit("a permuted context array was accepted")
-    except ValueError:
+    # the contexts in another order / a subset of them are not this clique (rank t must be ctxs[t]) and belong to a
+    # communicator the CALLER made — ABI 5 accepted any context array, so the call must still work: the roots are gathered through
+    # the host; only the resident variant, which has no host path, refuses (P252_ERR_COMM)
+    assert np.array_equal(multi.merkle4_tree_multi_device(ctxs[::-1], tag, d, per), exp)
+    if world > 2:
+        sub = oracle.merkle4_tree(tag, np.concatenate(lv[:2]))[0]
+        assert np.array_equal(multi.merkle4_tree_multi_device(ctxs[:2], tag, d[:2], per), sub)
+    try:
+        C.merkle4_tree_multi_device_resident(ctxs[::-1], tag, d, per, d_roots)
+        raise SystemExit("the resident variant accepted contexts of a foreign communicator")
+    except P.DeviceError:
         pass
+    assert np.array_equal(multi.merkle4_tree_multi_device(ctxs, tag, d, per), exp)  # and the caller's clique is intact
     for c in comms:
         c.destroy()
     for c in ctxs:
@@ -109,11 +117,27 @@ try:
     raise SystemExit("contexts that already belong to the library-made communicator were accepted")
 except ValueError:
     pass
+# ADVICE r4 (the regression of ABI 6): another count / order / subset of contexts that sit in a LIBRARY-made communicator — the
+# pattern of a shared `ctxs` fixture: ctxs[:8], then ctxs[:4], ctxs[:2], a permutation, all 8 again.  The library tears its own
+# cliques down and makes one over the array at hand; every call returns the oracle's root.
+for sel in (list(range(4)), [0, 1], [3, 2, 1, 0], [5, 6, 7], list(range(8))):
+    exp_sel = oracle.merkle4_tree(tag, np.concatenate([lv[t] for t in sel]))[0]
+    assert np.array_equal(multi.merkle4_tree_multi_device([ctxs[t] for t in sel], tag, [d[t] for t in sel], 4 ** 4), exp_sel), sel
+d_res = [torch.zeros(4, dtype=torch.int64, device="cuda:0") for _ in range(3)]
+C.merkle4_tree_multi_device_resident(ctxs[2:5], tag, d[2:5], 4 ** 4, d_res)  # the resident variant re-forms the clique as well
+torch.cuda.synchronize()
+assert all(np.array_equal(r.cpu().numpy().view(np.uint64), oracle.merkle4_tree(tag, np.concatenate(lv[2:5]))[0]) for r in d_res)
+# one context: no communicator is made at all (nothing to exchange), and the context is not tied to a hidden one
+solo = P.Context(0)
+assert np.array_equal(multi.merkle4_tree_multi_device([solo], tag, d[:1], 4 ** 4), oracle.merkle4_tree(tag, lv[0])[0])
+own = C.Comm.create_all([solo])
+own[0].destroy()
+solo.close()
 for c in ctxs:
     c.close()
 ctxs = [P.Context(0) for _ in range(8)]  # and again with fresh contexts: nothing of the first clique is left behind
 assert np.array_equal(multi.merkle4_tree_multi_device(ctxs, tag, d, 4 ** 4), oracle.merkle4_tree(tag, np.concatenate(lv))[0])
 for c in ctxs:
     c.close()
-report["communicator created on first use by p252_merkle4_tree_multi_device, destroyed with its contexts"] = "ok, twice"
+report["communicator created on first use by p252_merkle4_tree_multi_device, re-formed for other context arrays, destroyed with its contexts"] = "ok, twice"
 print(json.dumps(report))

@@ -111,12 +111,19 @@ def test_multi_device_entry_point_makes_its_own_communicator(gpu_ctx, oracle_mod
     a, b = P.Context(0), P.Context(0)
     try:
         assert np.array_equal(multi.merkle4_tree_multi_device([a], tag, d[:1], per), oracle_mod.merkle4_tree(tag, lv[:per])[0])
-        with pytest.raises(ValueError):  # the library-made communicator holds the context now
-            C.Comm.create_all([a])
         d_roots = [torch.zeros(4, dtype=torch.int64, device="cuda:0")]
         C.merkle4_tree_multi_device_resident([a], tag, d[:1], per, d_roots)
         torch.cuda.synchronize()
         assert np.array_equal(d_roots[0].cpu().numpy().view(np.uint64), oracle_mod.merkle4_tree(tag, lv[:per])[0])
+        # ONE context has nothing to exchange — no communicator is created for it, so it is not tied to a hidden
+        # one and may join the caller's; with the caller's communicator in place the same calls take the RCCL path (real backend)
+        own = C.Comm.create_all([a])
+        assert np.array_equal(multi.merkle4_tree_multi_device([a], tag, d[:1], per), oracle_mod.merkle4_tree(tag, lv[:per])[0])
+        d_roots[0].zero_()
+        C.merkle4_tree_multi_device_resident([a], tag, d[:1], per, d_roots)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_roots[0].cpu().numpy().view(np.uint64), oracle_mod.merkle4_tree(tag, lv[:per])[0])
+        own[0].destroy()
         if torch.cuda.device_count() < 2:
             c2 = P.Context(0)
             with pytest.raises(P.DeviceError):

@@ -1,0 +1,239 @@
+"""Round 5: the asynchronous builders are re-entrant across STREAMS of one context (the reference is
+re-entrant by construction: `const` tables, borrows only — src/hash.rs:92-96); library-owned copies of secrets are wiped (the
+reference builds with `zeroize`, Cargo.toml:14; src/encryption.rs:62-95); Hash::finalize_truncated (src/hash.rs:164-183, 203-210)
+is ONE launch — the digest kernels' own output stage — asserted on a kernel trace."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to("cuda:0")
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+# ---------------------------------------------------------------------------------------------- item 2: streams of ONE context
+def test_two_root_only_builds_on_two_streams_of_one_context(gpu_ctx, oracle_mod):
+    """two DIFFERENT 4^8-leaf root-only builds issued back to back on two torch streams of ONE context, 50 times: round 4 shared
+    one ping-pong scratch per context between them (api.cpp d_lvl) and returned wrong roots, silently"""
+    import torch
+    import poseidon252_amd as P
+    tag = P.merkle4_tag()
+    n = 4 ** 8
+    la, lb = oracle_mod.fill_random(0x51, n), oracle_mod.fill_random(0x52, n)
+    ea, eb = oracle_mod.merkle4_tree(tag, la)[0], oracle_mod.merkle4_tree(tag, lb)[0]
+    da, db = _dev(la), _dev(lb)
+    ra = torch.zeros((50, 4), dtype=torch.int64, device="cuda:0")
+    rb = torch.zeros((50, 4), dtype=torch.int64, device="cuda:0")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for i in range(50):
+        with torch.cuda.stream(s1):
+            gpu_ctx.merkle4_tree_device(tag, da, n, ra[i], None)
+        with torch.cuda.stream(s2):
+            gpu_ctx.merkle4_tree_device(tag, db, n, rb[i], None)
+    torch.cuda.synchronize()
+    assert np.array_equal(_host(ra), np.tile(ea, (50, 1))), "stream 1's roots differ from the oracle's"
+    assert np.array_equal(_host(rb), np.tile(eb, (50, 1))), "stream 2's roots differ from the oracle's"
+
+
+def test_more_streams_than_scratch_pairs_and_forests(gpu_ctx, oracle_mod):
+    """six streams on one context (the context keeps four scratch pairs: the fifth and sixth stream take over the least recently
+    used pair behind an event), trees of different sizes and a forest in the mix, three rounds: every root equals the oracle's"""
+    import torch
+    import poseidon252_amd as P
+    tag = P.merkle4_tag()
+    sizes = [4 ** 7, 4 ** 6, 4 ** 7, 5000, 4 ** 5, 4 ** 7]
+    leaves = [oracle_mod.fill_random(0x60 + i, m) for i, m in enumerate(sizes)]
+    exp = [oracle_mod.merkle4_tree(tag, lv)[0] for lv in leaves]
+    d = [_dev(lv) for lv in leaves]
+    streams = [torch.cuda.Stream() for _ in sizes]
+    roots = torch.zeros((3, len(sizes), 4), dtype=torch.int64, device="cuda:0")
+    per, n_trees = 4 ** 4, 64
+    fl = oracle_mod.fill_random(0x6f, per * n_trees)
+    d_fl = _dev(fl)
+    f_roots = torch.zeros((3, n_trees, 4), dtype=torch.int64, device="cuda:0")
+    fs = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                gpu_ctx.merkle4_tree_device(tag, d[i], sizes[i], roots[rnd, i], None)
+        with torch.cuda.stream(fs):
+            gpu_ctx.merkle4_forest_device(tag, d_fl, n_trees, per, f_roots[rnd])
+    torch.cuda.synchronize()
+    got = _host(roots).reshape(3, len(sizes), 4)
+    for rnd in range(3):
+        for i in range(len(sizes)):
+            assert np.array_equal(got[rnd, i], exp[i]), (rnd, i)
+    fr = _host(f_roots).reshape(3, n_trees, 4)
+    for t in (0, 17, n_trees - 1):
+        e = oracle_mod.merkle4_tree(tag, fl[t * per:(t + 1) * per])[0]
+        assert all(np.array_equal(fr[rnd, t], e) for rnd in range(3)), t
+
+
+def test_sharded_builds_of_one_communicator_on_two_streams(gpu_ctx, oracle_mod):
+    """a communicator's d_sub / d_roots / d_top are one set: builds queued on two streams are ordered by an event, never concurrent
+     — world = 1 on the real backend, two different leaf sets, 20 times"""
+    import torch
+    import poseidon252_amd as P
+    from poseidon252_amd import comm as C
+    tag = P.merkle4_tag()
+    n = 4 ** 7
+    la, lb = oracle_mod.fill_random(0x71, n), oracle_mod.fill_random(0x72, n)
+    ea, eb = oracle_mod.merkle4_tree(tag, la)[0], oracle_mod.merkle4_tree(tag, lb)[0]
+    da, db = _dev(la), _dev(lb)
+    ctx = P.Context(0)
+    c = C.Comm.create_rank(ctx, 0, 1, lambda b: b)
+    ra = torch.zeros((20, 4), dtype=torch.int64, device="cuda:0")
+    rb = torch.zeros((20, 4), dtype=torch.int64, device="cuda:0")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for i in range(20):
+        with torch.cuda.stream(s1):
+            c.merkle4_tree_sharded_device(tag, da, n, ra[i])
+        with torch.cuda.stream(s2):
+            c.merkle4_tree_sharded_device(tag, db, n, rb[i])
+    torch.cuda.synchronize()
+    assert np.array_equal(_host(ra), np.tile(ea, (20, 1))) and np.array_equal(_host(rb), np.tile(eb, (20, 1)))
+    c.destroy()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------- item 3: secret hygiene
+@pytest.mark.parametrize("n,length", [(300, 2), (5000, 7), (70000, 42)])  # 70,000 x 42 scalars: through the staging lanes, several chunks
+def test_host_encrypt_and_decrypt_leave_nothing_in_the_context(oracle_mod, n, length):
+    """shared secrets, nonces and plaintexts of p252_encrypt_batch / p252_decrypt_batch (host buffers) are copied into the
+    context's device scratch or its page-locked staging lanes: both are zero again when the call returns"""
+    import poseidon252_amd as P
+    from poseidon252_amd import encryption as Enc
+    ctx = P.Context(0)
+    try:
+        assert ctx.scratch_residue() == 0  # a fresh context owns nothing yet
+        msgs = oracle_mod.fill_random(0x81 + n, n * length).reshape(n, length, 4)
+        secrets = oracle_mod.fill_random(0x82 + n, n * 2).reshape(n, 2, 4)
+        nonces = oracle_mod.fill_random(0x83 + n, n).reshape(n, 4)
+        ciphers = Enc.encrypt_batch(msgs, secrets, nonces, ctx=ctx)
+        assert ctx.scratch_residue() <= 64 * 8, "encrypt left data in library-owned buffers"  # (only the call table: kind/len words, no secret)
+        back, ok = Enc.decrypt_batch(ciphers, secrets, nonces, ctx=ctx)
+        assert ctx.scratch_residue() <= 64 * 8, "decrypt left data in library-owned buffers"
+        assert bool(np.all(ok)) and np.array_equal(back.reshape(msgs.shape), msgs)
+        idx = np.arange(0, n, max(1, n // 64))
+        tag = Enc.encryption_tag(length)
+        assert np.array_equal(np.asarray(ciphers).reshape(n, length + 1, 4)[idx],
+                              oracle_mod.encrypt_batch(tag, np.ascontiguousarray(msgs[idx]), np.ascontiguousarray(secrets[idx]), np.ascontiguousarray(nonces[idx])))
+        # hashing calls do not wipe (their inputs are public): the scratch holds data until p252_wipe / p252_destroy
+        hb = P.HashBatch(P.Domain.Other, 5, ctx=ctx)
+        hb.digest(oracle_mod.fill_random(0x84, 5 * 2000).reshape(2000, 5, 4))
+        assert ctx.scratch_residue() > 2000 * 5 * 16
+        ctx.wipe()
+        assert ctx.scratch_residue() == 0
+        # ... and the context works as before after a wipe (the call table is uploaded again)
+        assert np.array_equal(Enc.encrypt_batch(msgs[:50], secrets[:50], nonces[:50], ctx=ctx), ciphers[:50])
+    finally:
+        ctx.close()
+
+
+def test_wipe_covers_level_scratch_and_staging_lanes(oracle_mod):
+    import torch
+    import poseidon252_amd as P
+    ctx = P.Context(0)
+    try:
+        tag = P.merkle4_tag()
+        lv = oracle_mod.fill_random(0x91, 4 ** 7)
+        root = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ctx.merkle4_tree_device(tag, _dev(lv), 4 ** 7, root, None)  # root-only: the levels ping-pong in context-owned scratch
+        torch.cuda.synchronize()
+        big = oracle_mod.fill_random(0x92, 4 * (1 << 19)).reshape(-1, 4, 4)  # 64 MiB of pageable input: staging lanes
+        P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx).digest(big)
+        assert ctx.scratch_residue() > (4 ** 6) * 16
+        ctx.wipe()
+        assert ctx.scratch_residue() == 0
+        assert np.array_equal(_host(root), oracle_mod.merkle4_tree(tag, lv)[0])
+    finally:
+        ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------- item 5: fused truncation
+@pytest.mark.parametrize("domain,item_len,out_len,n", [("Merkle4", 4, 1, 3000), ("Merkle4", 4, 1, 70000), ("Merkle2", 2, 1, 9000),
+                                                       ("Other", 5, 1, 300),   # tests/hash.rs:188-203: 5 inputs, truncated
+                                                       ("Other", 5, 1, 20000), ("Other", 42, 5, 9001), ("Other", 3, 7, 100), ("Other", 42, 5, 64)])
+def test_digest_truncated_is_the_fused_output_stage(gpu_ctx, oracle_mod, domain, item_len, out_len, n):
+    """every kernel family's truncating build (lane groups, one lane; whole-line fetches; single-permutation digests) against the
+    oracle's rule applied to the oracle's digests, host and device buffers, and against the two-launch form"""
+    import torch
+    import poseidon252_amd as P
+    hb = P.HashBatch(getattr(P.Domain, domain), item_len, output_len=out_len, ctx=gpu_ctx)
+    m = oracle_mod.fill_random(0xa0 + n + item_len, n * item_len).reshape(n, item_len, 4)
+    full = oracle_mod.hash_batch(hb.tag, m, item_len, hb.out_len, threads=8).reshape(-1, 4)
+    exp = np.stack([oracle_mod.truncate250(v) for v in full]).reshape(n, hb.out_len, 4)
+    assert np.array_equal(hb.digest_truncated(m), exp)
+    d = hb.digest_truncated(_dev(m))
+    torch.cuda.synchronize()
+    assert np.array_equal(_host(d).reshape(exp.shape), exp)
+    two = hb.digest(_dev(m))
+    gpu_ctx.truncate250_device(two, two, two.numel() // 4)
+    torch.cuda.synchronize()
+    assert torch.equal(two, d)
+    for v in _host(d).reshape(-1, 4)[:50]:  # the definition: a value below 2^250
+        assert oracle_mod.limbs_to_int(v) < (1 << 250)
+
+
+def test_truncated_edge_values(gpu_ctx, oracle_mod):
+    """outputs whose canonical value has bits above 2^250 set / is tiny: the mask and the Montgomery-form drop on special inputs
+    (the all-zero message, p - 1 everywhere)"""
+    import poseidon252_amd as P
+    hb = P.HashBatch(P.Domain.Merkle4, 4, ctx=gpu_ctx)
+    specials = np.stack([np.stack([oracle_mod.mont_from_int(v)] * 4) for v in (0, 1, oracle_mod.P - 1, 1 << 250, (1 << 254) + 12345)])
+    m = np.concatenate([specials, oracle_mod.fill_random(0xb1, 4 * 27).reshape(27, 4, 4)])
+    full = oracle_mod.hash_batch(hb.tag, m, 4, 1).reshape(-1, 4)
+    got = hb.digest_truncated(m).reshape(-1, 4)
+    for g, f in zip(got, full):
+        canonical = oracle_mod.limbs_to_int(f) * pow(1 << 256, -1, oracle_mod.P) % oracle_mod.P
+        assert oracle_mod.limbs_to_int(g) == canonical & ((1 << 250) - 1)
+
+
+def test_digest_truncated_on_device_tensors_issues_one_kernel(gpu_ctx, tmp_path):
+    """VERDICT r4 item 5, the kernel-trace assertion: HashBatch.digest_truncated on device tensors = ONE kernel of this library
+    (the truncating build of the digest kernel), no k_to_canonical, for both the single-permutation and the sponge family"""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        pytest.skip("rocprofv3 not on this box")
+    script = tmp_path / "one_launch.py"
+    script.write_text(
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch, poseidon252_amd as P\n"
+        "from poseidon252_amd import synth\n"
+        "ctx = P.Context(0)\n"
+        "a = synth.splitmix_scalars(1, 4 << 15, torch.device('cuda:0'))\n"
+        "b = synth.splitmix_scalars(2, 42 << 14, torch.device('cuda:0'))\n"
+        "torch.cuda.synchronize()\n"
+        "P.HashBatch(P.Domain.Merkle4, 4, ctx=ctx).digest_truncated(a)\n"
+        "P.HashBatch(P.Domain.Other, 42, output_len=5, ctx=ctx).digest_truncated(b)\n"
+        "torch.cuda.synchronize()\n" % ROOT)
+    out = tmp_path / "trace"
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run([rocprof, "--kernel-trace", "--output-format", "csv", "-d", str(out), "-o", "kt", "--", sys.executable, str(script)],
+                       cwd="/tmp", env=env, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    files = glob.glob(str(out / "**" / "*kernel_trace.csv"), recursive=True)
+    assert files, os.listdir(out)
+    import csv
+    names = [row["Kernel_Name"] for f in files for row in csv.DictReader(open(f))]
+    ours = [n for n in names if "p252" in n]
+    hashing = [n for n in ours if "k_synth" not in n and "splitmix" not in n]
+    assert len(hashing) == 2, hashing
+    assert sum("k_merkle4_trunc" in n for n in hashing) == 1 and sum("k_sponge_lines_trunc" in n for n in hashing) == 1, hashing
+    assert not any("k_to_canonical" in n for n in names)
