@@ -78,9 +78,11 @@ PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KERNEL_SOURCES = ("kernels.hip", "fr29.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h")
 
 
-def kernel_sources_sha256():
+def kernel_sources_sha256(kernel=None):
+    """digest of the sources `kernel` is compiled from: the hashing kernels' files; the extraction kernel's own file on top for it
+    (a change of csrc/openings.hip makes only ITS counter passes stale)"""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES + (("openings.hip",) if kernel and "openings" in kernel else ()):
         h.update(open(os.path.join(ROOT, "poseidon252_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -138,7 +140,7 @@ def pmc_profile(kernel):
     except (OSError, ValueError):
         return None
     d["source"] = os.path.relpath(path, ROOT)
-    d["stale"] = d.get("kernel_sources_sha256") != kernel_sources_sha256()
+    d["stale"] = d.get("kernel_sources_sha256") != kernel_sources_sha256(kernel)
     return d
 
 

@@ -12,6 +12,8 @@
 // Algorithmic bytes per (opening, level): 96 read + 96 written + 1 position byte (+ 64 per opening for the leaf).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "openings.h"
 
 namespace p252 {
@@ -33,11 +35,35 @@ __device__ __forceinline__ uint4 load_or_zero(const uint4* __restrict__ base, si
 // IDX = uint32_t whenever the launch has fewer than 2^32 lanes (6 k depth < 2^32: every realistic batch) — the lane's record and
 // level then come from 32-bit divisions; size_t otherwise
 // ARITY 4: three siblings per level (six 16-byte pieces per record); ARITY 2 (Domain::Merkle2 trees): one sibling (two pieces)
-template <class IDX, unsigned ARITY>
+// FAST (round 5; 32-bit lane indices only): what the counters of round 4's kernel pointed at was not memory (0.41-0.43 of HBM peak by
+// FETCH_SIZE / WRITE_SIZE) but per-lane integer work around ONE 16-byte load and ONE 16-byte store — a 32-bit division by `depth`
+// (~30 instructions with a quarter-rate reciprocal) and a DIVERGENT loop of up to `depth` trips for the level's offset (lanes of a
+// wave sit on ~11 different levels).  FAST: the division is a multiply-shift with a host-computed reciprocal (exact for every
+// record index a 32-bit launch can hold), and the `depth` (offset, count) pairs are computed ONCE per block by its first `depth`
+// lanes into LDS (512 B) and read back with one ds_read per lane.
+struct LevelRef {
+    unsigned long long first;  // index of the level's first 16-byte word, relative to `levels` (level 0: the leaves, unused)
+    unsigned long long cnt;    // nodes in the level
+};
+template <class IDX, unsigned ARITY, bool FAST = false>
 __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restrict__ leaves, size_t n_leaves, const uint4* __restrict__ levels,
                                                           const uint32_t* __restrict__ index, size_t k, unsigned depth,
                                                           uint4* __restrict__ leaves_out, uint4* __restrict__ siblings,
-                                                          uint8_t* __restrict__ positions, unsigned* __restrict__ n_bad) {
+                                                          uint8_t* __restrict__ positions, unsigned* __restrict__ n_bad,
+                                                          unsigned long long inv_depth) {
+    __shared__ LevelRef lvl[FAST ? 64 : 1];
+    if (FAST) {  // (before any lane leaves: every lane of the block reaches the barrier)
+        if (threadIdx.x < depth && threadIdx.x < 64) {
+            unsigned long long first = 0, cnt = n_leaves;
+            for (unsigned j = 0; j < threadIdx.x; ++j) {
+                first = j == 0 ? 0 : first + 2 * cnt;
+                cnt = (cnt + ARITY - 1) >> (ARITY == 4 ? 2 : 1);
+            }
+            lvl[threadIdx.x].first = first;
+            lvl[threadIdx.x].cnt = cnt;
+        }
+        __syncthreads();
+    }
     const IDX t = (IDX)blockIdx.x * 256 + threadIdx.x;  // = the index of the 16-byte word of `siblings` this lane stores
     if (depth == 0) {  // a single-leaf tree has no levels: two lanes per opening copy the leaf
         if (t >= 2 * k) return;
@@ -51,7 +77,8 @@ __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restric
     if (t >= (IDX)(k * depth * PIECES)) return;
     const IDX rec = t / PIECES;
     const unsigned piece = (unsigned)(t - rec * PIECES), sib = piece >> 1, half = piece & 1u;
-    const IDX i = rec / (IDX)depth;
+    // FAST: rec < 2^32 / PIECES and depth <= 64: floor(rec * ceil(2^40 / depth) / 2^40) == rec / depth exactly
+    const IDX i = FAST ? (IDX)(((unsigned long long)rec * inv_depth) >> 40) : rec / (IDX)depth;
     const unsigned l = (unsigned)(rec - i * depth);
     const size_t leaf = index[i];
     const bool bad = leaf >= n_leaves;
@@ -62,9 +89,15 @@ __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restric
     // the array of level l (level 0 = the leaves) and its length: n_0 = n_leaves, n_{l+1} = ceil(n_l / 4)
     const uint4* nodes = leaves;
     size_t cnt = n_leaves;
-    for (unsigned j = 0; j < l; ++j) {  // (at most `depth` trips of two integer operations: nothing beside the line fetch)
-        nodes = j == 0 ? levels : nodes + 2 * cnt;
-        cnt = (cnt + ARITY - 1) >> SHIFT;
+    if (FAST) {
+        const LevelRef r = lvl[l];
+        nodes = l == 0 ? leaves : levels + r.first;
+        cnt = r.cnt;
+    } else {
+        for (unsigned j = 0; j < l; ++j) {  // (at most `depth` trips of two integer operations, divergent within a wave)
+            nodes = j == 0 ? levels : nodes + 2 * cnt;
+            cnt = (cnt + ARITY - 1) >> SHIFT;
+        }
     }
     const size_t node = leaf >> (SHIFT * l);
     const unsigned p = (unsigned)(node & (ARITY - 1));
@@ -81,14 +114,24 @@ static hipError_t launch_openings(const void* leaves, size_t n_leaves, const voi
     if (k == 0) return hipSuccess;
     const size_t lanes = depth ? k * depth * 2 * (ARITY - 1) : 2 * k;
     const dim3 grid((unsigned)((lanes + 255) / 256));
-    if (lanes + 256 <= 0xffffffffull)
+    // P252_OPENINGS_FAST=0: round 4's kernel (division + per-lane level loop) — kept for the A/B of profiles/r05_openings_extract.txt
+    static const bool fast = [] {
+        const char* e = std::getenv("P252_OPENINGS_FAST");
+        return !(e && e[0] == '0');
+    }();
+    const unsigned long long inv_depth = depth ? ((1ull << 40) / depth) + 1 : 0;
+    if (lanes + 256 <= 0xffffffffull && fast && depth >= 1 && depth <= 64)
+        hipLaunchKernelGGL((k_merkle4_openings<uint32_t, ARITY, true>), grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
+                           static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
+                           static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad), inv_depth);
+    else if (lanes + 256 <= 0xffffffffull)
         hipLaunchKernelGGL((k_merkle4_openings<uint32_t, ARITY>), grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
                            static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
-                           static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad));
+                           static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad), inv_depth);
     else
         hipLaunchKernelGGL((k_merkle4_openings<size_t, ARITY>), grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
                            static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),
-                           static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad));
+                           static_cast<uint4*>(siblings), static_cast<uint8_t*>(positions), static_cast<unsigned*>(n_bad), inv_depth);
     return hipGetLastError();
 }
 

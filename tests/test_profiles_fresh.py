@@ -16,6 +16,8 @@ def test_hash_functions_agree():
     import pmc_summary
     assert bench.KERNEL_SOURCES == pmc_summary.KERNEL_SOURCES
     assert bench.kernel_sources_sha256() == pmc_summary.kernel_sources_sha256()
+    # the extraction kernel has a source file of its own: only ITS counter passes go stale with it
+    assert bench.kernel_sources_sha256("k_merkle4_openings") == pmc_summary.kernel_sources_sha256("k_merkle4_openings") != bench.kernel_sources_sha256()
 
 
 def test_default_line_reads_counter_passes_of_the_current_sources():

@@ -18,9 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ("kernels.hip", "fr29.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h")  # = bench.py's
 
 
-def kernel_sources_sha256():
+def kernel_sources_sha256(kernel=None):
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES + (("openings.hip",) if kernel and "openings" in kernel else ()):  # = bench.py's rule
         h.update(open(os.path.join(ROOT, "poseidon252_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -62,7 +62,7 @@ def main():
     for k in sorted(avg):
         print("%-24s %.6g" % (k, avg[k]))
     out = {"kernel": kern, "units_per_launch": units, "counters": avg, "algorithmic_bytes_per_unit": bpu, "per_step": per_step,
-           "kernel_sources_sha256": kernel_sources_sha256()}
+           "kernel_sources_sha256": kernel_sources_sha256(kern)}
     print("# kernel sources sha256 %s" % out["kernel_sources_sha256"][:16])
     if durs:
         durs.sort()
