@@ -59,8 +59,16 @@ def test_data_movement_kernels_use_no_scratch(tmp_path):
     names = re.findall(r"Function Name: (\S+)", proc.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", proc.stderr)]
     vgprs = [int(x) for x in re.findall(r"\bVGPRs: (\d+)", proc.stderr)]
-    assert len(names) == 4 and len(scratch) == 4 and len(vgprs) == 4, proc.stderr[-1500:]  # {uint32, size_t} lane index x {arity 4, arity 2}
-    assert scratch == [0, 0, 0, 0] and max(vgprs) <= 32, (names, scratch, vgprs)
+    # {uint32 FAST (multiply-shift + level table in LDS, round 5), uint32, size_t} lane index x {arity 4, arity 2}
+    assert len(names) == 6 and len(scratch) == 6 and len(vgprs) == 6, proc.stderr[-1500:]
+    assert scratch == [0] * 6 and max(vgprs) <= 32, (names, scratch, vgprs)
+    # the FAST builds hold no division (v_rcp_iflag_f32 is the 32-bit udiv expansion's reciprocal) and read the level table from LDS
+    text = open(out).read()
+    for n in names:
+        body = text[text.index("\n" + n + ":"):]
+        body = body[:body.index("s_endpgm")]
+        fast = "ELb1EEE" in n
+        assert (body.count("v_rcp") == 0 and body.count("ds_read") + body.count("ds_load") >= 1) if fast else body.count("v_rcp") >= 1, n
     assert "scratch_" not in open(out).read()
 
 
