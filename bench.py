@@ -818,6 +818,18 @@ def roofline_of(W, launch_ms, clk_before, clk_after, sclk_sysfs=None):
 # builds the full record as before (every source, probe, nested model and note: `detail`), writes it to a side file next to
 # bench.py (--detail-file) and PRINTS a line of scalars only, whose length is bounded and asserted.
 LINE_BUDGET_BYTES = 6000
+# stdout carries exactly ONE line.  Libraries loaded into the ranks print to fd 1 on their own (RCCL's version banner at communicator
+# creation, HIP warnings): main() points fd 1 at stderr for the whole run and keeps the real stdout for the line (emit()).
+_REAL_STDOUT_FD = None
+
+
+def keep_stdout_for_the_line():
+    global _REAL_STDOUT_FD
+    if _REAL_STDOUT_FD is None:
+        sys.stdout.flush()
+        _REAL_STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
 ROOFLINE_SCALARS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_at_measured_clock", "frac_valu_issue", "macs_per_perm_executed",
                     "clock_ghz_measured", "launch_ms_mean", "units_per_launch", "traffic", "traffic_ratio", "frac_reference_schedule")
 SECONDARY_SCALARS = ("value", "unit", "units_per_gpu_per_step", "ms_per_step", "steps", "ms_per_step_rank_min", "ms_per_step_rank_max",
@@ -899,7 +911,11 @@ def emit(detail, detail_path):
         line["secondary"] = {k: {"value": v["value"], "ms_per_step": v["ms_per_step"], "frac": v["frac"]} for k, v in line["secondary"].items()}
         line["line_trimmed"] = True
         text = json.dumps(line, separators=(",", ":"))
-    print(text, flush=True)
+    if _REAL_STDOUT_FD is None:
+        print(text, flush=True)
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT_FD, (text + "\n").encode())
     return line
 
 
@@ -920,6 +936,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver); before the runtime loads
+    keep_stdout_for_the_line()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
