@@ -50,7 +50,7 @@ if "--long" in sys.argv:
     minutes = float(sys.argv[sys.argv.index("--long") + 1]) if len(sys.argv) > sys.argv.index("--long") + 1 else 5.0
     counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0, "tree updates": 0,
               "forest trees": 0, "sharded-tree leaves (RCCL, one rank)": 0,
-              "openings extracted on the device": 0}
+              "openings extracted on the device": 0, "fused truncated outputs": 0, "root-only builds on concurrent streams": 0}
     from poseidon252_amd import comm as C
     comm_ctx = P.Context(0)
     comm1 = C.Comm.create_rank(comm_ctx, 0, 1, lambda b: b)  # the library's RCCL communicator on the real backend (round 4)
@@ -61,7 +61,7 @@ if "--long" in sys.argv:
     while time.time() - t0 < 60 * minutes:
         it += 1
         seed = int(rng.integers(1, 1 << 30))
-        kind = it % 12
+        kind = it % 14
         n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 8193)), int(rng.integers(8193, 20000))]))
         if kind == 0:
             n = min(n, 12000)
@@ -182,6 +182,39 @@ if "--long" in sys.argv:
             assert np.array_equal(sib.cpu().numpy().view(np.uint64).reshape(h_sib.shape), h_sib) and np.array_equal(pos.cpu().numpy().reshape(h_pos.shape), h_pos), ("openings extract", leaves_n, k, seed)
             assert bool((roots == d_root.view(1, 4)).all()) and np.array_equal(d_root.cpu().numpy().view(np.uint64), oracle.merkle4_tree(mtag, lv)[0]), ("openings rehash", leaves_n, k, seed)
             counts["openings extracted on the device"] += k
+        elif kind == 12:  # round 5: finalize_truncated in the digest kernels' output stage, random shapes, host and device buffers
+            import torch
+            in_len, out_len = int(rng.choice([4, 2, int(rng.integers(1, 50))])), int(rng.integers(1, 10))
+            if in_len in (4, 2) and rng.integers(0, 2):
+                out_len = 1  # the single-permutation digest kernels
+            n = min(n, 40000 // in_len + 1)
+            tag = oracle.fill_random(seed + 1, 1).reshape(4)
+            msg = oracle.fill_random(seed, n * in_len).reshape(n, in_len, 4)
+            exp = P.truncate250(oracle.hash_batch(tag, msg, in_len, out_len, threads=8).reshape(-1, 4)).reshape(n, out_len, 4)
+            assert np.array_equal(ctx.hash_batch(tag, msg, in_len, out_len, truncated=True), exp), ("truncated host", n, in_len, out_len, seed)
+            d_out = torch.empty((n, out_len, 4), dtype=torch.int64, device="cuda")
+            ctx.hash_batch_device(tag, torch.from_numpy(msg.view(np.int64).copy()).cuda(), in_len, out_len, d_out, n, truncated=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint64).reshape(exp.shape), exp), ("truncated device", n, in_len, out_len, seed)
+            counts["fused truncated outputs"] += n * out_len
+        elif kind == 13:  # round 5: root-only builds queued on 2 .. 6 streams of ONE context at once (per-stream level scratch)
+            import torch
+            k = int(rng.integers(2, 7))
+            sizes = [int(rng.choice([4 ** int(rng.integers(1, 8)), int(rng.integers(1, 20000))])) for _ in range(k)]
+            lvs = [oracle.fill_random(seed + j, m) for j, m in enumerate(sizes)]
+            ds = [torch.from_numpy(lv.view(np.int64).copy()).cuda() for lv in lvs]
+            d_roots = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+            streams = [torch.cuda.Stream() for _ in range(k)]
+            torch.cuda.synchronize()
+            for rep in range(3):
+                for j in range(k):
+                    with torch.cuda.stream(streams[j]):
+                        ctx.merkle4_tree_device(mtag, ds[j], sizes[j], d_roots[j], None)
+            torch.cuda.synchronize()
+            got = d_roots.cpu().numpy().view(np.uint64)
+            for j in range(k):
+                assert np.array_equal(got[j], oracle.merkle4_tree(mtag, lvs[j])[0]), ("streams", sizes, j, seed)
+            counts["root-only builds on concurrent streams"] += 3 * k
         elif kind == 10:  # subtree -> ncclAllGather of the roots on the stream -> top levels, inside the library
             import torch
             leaves_n = 4 ** int(rng.integers(0, 10))

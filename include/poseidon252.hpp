@@ -83,6 +83,9 @@ class Context {
         ctx_.reset(c, p252_destroy);
     }
     p252_ctx* get() const { return ctx_.get(); }
+    // clears every scratch buffer the context owns (zeroize, Cargo.toml:14); the host-buffer encrypt / decrypt calls and the
+    // destructor do so themselves
+    void wipe() { detail::check(p252_wipe(ctx_.get()), ctx_.get(), "Context::wipe"); }
     static Context& default_context() {
         static Context c(0);
         return c;

@@ -100,6 +100,19 @@ int main() {
         JubJubRaw exp;
         p252o_truncate250(full[0].data(), exp.data());
         EXPECT(t.size() == 1 && t[0] == exp && (t[0][3] >> 58) == 0);
+        // the batched form (HashBatch::digest_truncated: one launch, the digest kernel's truncating output stage), tests/hash.rs:188-203 shape
+        HashBatch hb(Domain::Other, 5);
+        auto many = random_scalars(0xbeef + 5, 5 * 40);  // item 0 = `input` above
+        auto tb = hb.digest_truncated(many);
+        auto fb = hb.digest(many);
+        EXPECT(tb.size() == 40 && tb[0] == exp);
+        for (std::size_t i = 0; i < tb.size(); ++i) {
+            JubJubRaw e;
+            p252o_truncate250(fb[i].data(), e.data());
+            EXPECT(tb[i] == e);
+        }
+        Context::default_context().wipe();  // (and the context keeps working afterwards)
+        EXPECT(hb.digest_truncated(many) == tb);
     }
     // ---- output_len rules (hash.rs:111-115) and panics (hash.rs:124-137) ----
     {

@@ -12,6 +12,8 @@ mkdir -p "$O"
 python -m pytest tests -m gpu -q > "$O/gputest.txt" 2>&1
 tail -2 "$O/gputest.txt"
 python bench.py > "$O/bench.json" 2> "$O/bench.err"
+cp "$ROOT/bench_detail.json" "$O/bench_detail.json" 2>/dev/null   # the full record behind the printed line (bench.py --detail-file)
+wc -c "$O/bench.json"
 rm -rf "$ROOT/gpurun_out/ktrace_default"
 (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/ktrace_default" -o kt -- python "$ROOT/bench.py" --no-cpu-baseline > "$O/bench_under_ktrace.json" 2> "$O/bench_under_ktrace.err")
 db=$(find "$ROOT/gpurun_out/ktrace_default" -name "*.db" | head -1)
@@ -21,7 +23,7 @@ bash tools/run_pmc.sh sponge42 valu fetch write >> "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh tree fetch write >> "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh openings valu fetch write >> "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh encrypt valu fetch write >> "$O/run_pmc.log" 2>&1
-bash tools/run_pmc.sh extract fetch write >> "$O/run_pmc.log" 2>&1   # the HBM-bound extraction of openings (csrc/openings.hip)
+bash tools/run_pmc.sh extract valu wait tcp fetch write >> "$O/run_pmc.log" 2>&1   # the extraction of openings (csrc/openings.hip): what binds it
 LOG2N=12 bash tools/run_pmc.sh merkle4_digests valu >> "$O/run_pmc.log" 2>&1
 cp "$ROOT"/gpurun_out/summaries/* "$O/" 2>/dev/null
 for wl in tree forest sponge42 openings encrypt extract; do python bench.py --workload $wl --no-cpu-baseline > "$O/bench_$wl.json" 2>/dev/null; done
@@ -34,4 +36,7 @@ for wl in sponge42 openings encrypt; do python bench.py --workload $wl --log2n 1
 bash bench_tools/host_multi_sweep.sh 2>&1 | grep -v amdgpu.ids > "$O/host_path_multi.txt"
 python bench_tools/host_path_bench.py 2>&1 | grep -v amdgpu.ids > "$O/host_path.txt"
 python bench_tools/clock_probe_check.py 2>&1 | grep -v "amdgpu.ids\|sysfs" > "$O/clock_probe_check.txt"
+./bench_tools/copy_rate > "$O/copy_rate.txt" 2>&1   # the HBM yardstick on this box (16-byte copy, hipMemcpy D2D, no-arithmetic gather)
+timeout 400 python bench_tools/soak_check.py --long 4 2>&1 | grep -v "amdgpu.ids\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" > "$O/soak_long.txt"
+tail -3 "$O/soak_long.txt"
 ls "$O"
