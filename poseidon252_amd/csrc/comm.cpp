@@ -168,12 +168,6 @@ static std::vector<p252_comm*> clique_of(p252_ctx* const* ctxs, size_t n_ctx) {
     return v;
 }
 
-// why the last lazy communicator creation fell back to the host gather (diagnostics only; P252_OK was returned)
-static std::string& lazy_comm_error() {
-    static std::string e;
-    return e;
-}
-
 static bool distinct_devices(p252_ctx* const* ctxs, size_t n_ctx) {
     // (test-only: tests/test_comm_mock_ranks.py links the library against a mock RCCL that accepts several ranks on one device, to
     // run the multi-rank logic on a one-GPU box; real RCCL refuses such a communicator itself)
@@ -308,8 +302,7 @@ int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t t
                 for (p252_comm* m : members) free_comm(m, false);
             }
         int rc = create_all(ctxs, n_ctx, comms, /*owned=*/true);
-        if (rc) {  // no communicator to be had (ncclCommInitAll refused): the host gather still exists — use it, say why
-            lazy_comm_error() = ctxs[0]->err;
+        if (rc) {  // no communicator to be had (ncclCommInitAll refused): the host gather still exists — the caller takes it
             ctxs[0]->err.clear();
             return P252_OK;
         }
