@@ -17,7 +17,7 @@ wc -c "$O/bench.json"
 rm -rf "$ROOT/gpurun_out/ktrace_default"
 (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/ktrace_default" -o kt -- python "$ROOT/bench.py" --no-cpu-baseline > "$O/bench_under_ktrace.json" 2> "$O/bench_under_ktrace.err")
 db=$(find "$ROOT/gpurun_out/ktrace_default" -name "*.db" | head -1)
-[ -n "$db" ] && python tools/rocprof_summary.py "$db" "python bench.py --no-cpu-baseline (the default line: configs[1], then the secondary tree and sponge42)" 38 > "$O/bench_kernel_trace.txt"
+[ -n "$db" ] && python tools/rocprof_summary.py "$db" "python bench.py --no-cpu-baseline (the default line: configs[1], then the secondary workloads)" 38 50 > "$O/bench_kernel_trace.txt"
 bash tools/run_pmc.sh merkle4_digests valu stall ifetch icache dcache fetch write > "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh sponge42 valu fetch write >> "$O/run_pmc.log" 2>&1
 bash tools/run_pmc.sh tree fetch write >> "$O/run_pmc.log" 2>&1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 results.db (rocpd sqlite) into the text table kept under profiles/.
-usage: rocprof_summary.py <results.db> [title] [warmup_launches=10]"""
+usage: rocprof_summary.py <results.db> [title] [warmup_launches=10] [primary_steps=50]"""
 import sqlite3
 import sys
 
@@ -10,7 +10,26 @@ def short_name(name, width):
     return name.replace("(anonymous namespace)::", "").split("(")[0][-width:]
 
 
-def main(path, title="", warm=10):
+def primary_region(cur, steps):
+    """bench.py's PRIMARY workload is the first thing a run launches: wake-up, warm-up, 4 probe steps, `steps` TIMED launches, 4 probe
+    steps — all of one (kernel, grid) — and then its self-check, which launches something else.  Later launches of the same kernel and
+    grid (a 2^24-leaf tree's level of 2^20 nodes in the secondary workloads) do NOT belong to it: the per-grid average above mixes them
+    in, this section does not.  Returns (name, grid, durations of the timed launches) or None."""
+    rows = list(cur.execute("select name, grid_x, duration from kernels where name like '%p252::%' and name not like '%k_clock_probe%' order by start"))
+    if not rows:
+        return None
+    name, grid = rows[0][0], rows[0][1]
+    region = []
+    for n, g, d in rows:
+        if (n, g) != (name, grid):
+            break
+        region.append(d)
+    if len(region) < steps + 8:
+        return None
+    return name, grid, region[-(steps + 4):-4]
+
+
+def main(path, title="", warm=10, steps=50):
     db = sqlite3.connect(path)
     cur = db.cursor()
     print("# rocprofv3 --kernel-trace --stats summary%s" % ((": " + title) if title else ""))
@@ -42,6 +61,15 @@ def main(path, title="", warm=10):
         rest = durs[warm:] if len(durs) > warm + 1 else []
         print("%-44s %10d %7d %12.1f %12.1f %12s %12s" % (short_name(name, 42), grid, len(durs), sum(durs) / len(durs) / 1e3, min(durs) / 1e3,
                                                          len(rest) if rest else "-", ("%.1f" % (sum(rest) / len(rest) / 1e3)) if rest else "-"))
+    pr = primary_region(cur, steps)
+    if pr:
+        name, grid, durs = pr
+        print()
+        print("# the PRIMARY's timed region alone: the %d launches bench.py times (HIP events: roofline.launch_ms_mean), i.e. the launches of the run's first"
+              % steps)
+        print("# kernel and grid up to its self-check minus wake-up / warm-up / probe steps; later launches of the same grid (tree levels) excluded")
+        print("%-44s %10s %7s %12s %12s %12s" % ("kernel", "grid", "calls", "avg_us", "min_us", "max_us"))
+        print("%-44s %10d %7d %12.1f %12.1f %12.1f" % (short_name(name, 42), grid, len(durs), sum(durs) / len(durs) / 1e3, min(durs) / 1e3, max(durs) / 1e3))
     print()
     print("# per-kernel launch geometry / registers (first dispatch)")
     for r in cur.execute("select name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size from kernels group by name"):
@@ -58,4 +86,5 @@ def main(path, title="", warm=10):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", int(sys.argv[3]) if len(sys.argv) > 3 else 10)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", int(sys.argv[3]) if len(sys.argv) > 3 else 10,
+         int(sys.argv[4]) if len(sys.argv) > 4 else 50)
