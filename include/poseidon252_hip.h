@@ -40,7 +40,10 @@
  * levels in scratch owned by the context PER STREAM (up to four streams at once; a fifth takes over the least recently used
  * scratch behind an event — never concurrently), and a communicator's buffers are handed from one stream to the next behind
  * an event as well.  The one context-wide piece of state is the encryption call table: p252_{encrypt,decrypt}_batch_device
- * with another (variant, len) than the previous call drains the device before replacing it.  Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
+ * with another (variant, len) than the previous call drains the device before replacing it.
+ * HIP graphs: the `*_device` hashing and tree entry points do nothing but enqueue kernels (and one 32-byte copy) on `hip_stream`, so
+ * they can be stream-captured into a hipGraph and replayed on new data in the same buffers; call once outside the capture first
+ * (context-owned scratch and the encryption call table are allocated / uploaded on first use, which a capture cannot do).  Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
  * or the p252_*_multi entry points below, which take the array of contexts and shard inside the library; batches
  * shard with no inter-GPU dependence.
  */

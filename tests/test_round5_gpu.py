@@ -238,3 +238,64 @@ def test_digest_truncated_on_device_tensors_issues_one_kernel(gpu_ctx, tmp_path)
     assert len(hashing) == 2, hashing
     assert sum("k_merkle4_trunc" in n for n in hashing) == 1 and sum("k_sponge_lines_trunc" in n for n in hashing) == 1, hashing
     assert not any("k_to_canonical" in n for n in names)
+
+
+# ---------------------------------------------------------------------------------------------- HIP graphs
+def test_device_entry_points_capture_into_a_hip_graph(gpu_ctx, oracle_mod):
+    """the `_device` entry points only enqueue kernels on the stream they are given, so a caller can capture them into a hipGraph
+    (here through torch.cuda.CUDAGraph, which captures torch's current stream — the stream the binding launches on) and replay the
+    graph on new data: digests (both kernel families), a 42 -> 5 sponge, the truncated form, a tree build with caller-owned levels
+    and a root-only one (its per-stream scratch exists after the warm-up call, so the capture allocates nothing).  Replays on fresh
+    inputs equal the oracle."""
+    import torch
+    import poseidon252_amd as P
+    tag4 = P.merkle4_tag()
+    hb5 = P.HashBatch(P.Domain.Other, 42, output_len=5, ctx=gpu_ctx)
+    n_small, n_big, n_sp, n_leaves = 3000, 20000, 9000, 4 ** 6
+    d_small = torch.zeros((n_small, 4, 4), dtype=torch.int64, device="cuda:0")
+    d_big = torch.zeros((n_big, 4, 4), dtype=torch.int64, device="cuda:0")
+    d_sp = torch.zeros((n_sp, 42, 4), dtype=torch.int64, device="cuda:0")
+    d_lv = torch.zeros((n_leaves, 4), dtype=torch.int64, device="cuda:0")
+    o_small = torch.zeros((n_small, 4), dtype=torch.int64, device="cuda:0")
+    o_big = torch.zeros((n_big, 4), dtype=torch.int64, device="cuda:0")
+    o_trunc = torch.zeros((n_big, 4), dtype=torch.int64, device="cuda:0")
+    o_sp = torch.zeros((n_sp, 5, 4), dtype=torch.int64, device="cuda:0")
+    o_root = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    o_levels = torch.zeros((P.levels_len(n_leaves), 4), dtype=torch.int64, device="cuda:0")
+    o_root2 = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+
+    def work():
+        gpu_ctx.hash_batch_device(tag4, d_small, 4, 1, o_small, n_small)
+        gpu_ctx.hash_batch_device(tag4, d_big, 4, 1, o_big, n_big)
+        gpu_ctx.hash_batch_device(tag4, d_big, 4, 1, o_trunc, n_big, truncated=True)
+        gpu_ctx.hash_batch_device(hb5.tag, d_sp, 42, 5, o_sp, n_sp)
+        gpu_ctx.merkle4_tree_device(tag4, d_lv, n_leaves, o_root, o_levels)
+        gpu_ctx.merkle4_tree_device(tag4, d_lv, n_leaves, o_root2, None)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # (warm-up outside the capture, as torch asks)
+        work()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        work()
+    for rep in range(3):
+        xs = oracle_mod.fill_random(0xd0 + rep, 4 * n_small).reshape(n_small, 4, 4)
+        xb = oracle_mod.fill_random(0xd4 + rep, 4 * n_big).reshape(n_big, 4, 4)
+        sp = oracle_mod.fill_random(0xd8 + rep, 42 * n_sp).reshape(n_sp, 42, 4)
+        lv = oracle_mod.fill_random(0xdc + rep, n_leaves)
+        for dst, src in ((d_small, xs), (d_big, xb), (d_sp, sp), (d_lv, lv)):
+            dst.copy_(_dev(src).view(dst.shape))
+        for o in (o_small, o_big, o_trunc, o_sp, o_root, o_levels, o_root2):
+            o.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(_host(o_small), oracle_mod.hash_batch(tag4, xs, 4, 1, threads=8).reshape(-1, 4)), rep
+        eb = oracle_mod.hash_batch(tag4, xb, 4, 1, threads=8).reshape(-1, 4)
+        assert np.array_equal(_host(o_big), eb), rep
+        assert np.array_equal(_host(o_trunc), P.truncate250(eb)), rep
+        idx = np.arange(0, n_sp, 37)
+        assert np.array_equal(_host(o_sp).reshape(n_sp, 5, 4)[idx], oracle_mod.hash_batch(hb5.tag, np.ascontiguousarray(sp[idx]), 42, 5, threads=8)), rep
+        e_root, e_levels, _ = oracle_mod.merkle4_tree(tag4, lv, want_levels=True)
+        assert np.array_equal(_host(o_root), e_root) and np.array_equal(_host(o_levels), e_levels) and np.array_equal(_host(o_root2), e_root), rep
