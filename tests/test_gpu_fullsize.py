@@ -203,3 +203,48 @@ def test_config5_per_gpu_share_2pow24_leaves_all_levels(gpu_ctx, oracle_mod):
     n01 = oracle_mod.hash_batch(tag, roots.reshape(2, 4, 4), 4, 1).reshape(2, 4)
     top = oracle_mod.hash_batch(tag, np.concatenate([n01, zero]).reshape(1, 4, 4), 4, 1).reshape(4)
     assert np.array_equal(root8, top)  # 8 subtrees + 3 top permutations: 44,739,243 in all at full size
+
+
+@pytest.mark.parametrize("log2n", [30, 32])
+def test_beyond_4GiB_leaves_in_one_buffer(gpu_ctx, oracle_mod, log2n):
+    """(log2n = 32 — 2^32 leaves = 128 GiB in one buffer, ~180 GiB in all, more leaves than a uint32 counts — runs with P252_TEST_HUGE=1.)
+    Maximum sizes (MI355X: 288 GB of HBM per GPU — shards are sized for it): 2^30 leaves = 32 GiB in ONE buffer, 64 x one GPU's
+    share of BASELINE configs[4].  Every index on this path must be 64-bit: 2^28 digests in one launch (8 GiB out), the 15-level
+    tree over the 2^30 leaves (357,913,941 permutations, root only: 10 GiB of per-stream level scratch) and the forest of 2^18 trees
+    of 4^6 leaves over the same buffer.  Checked through size-independent properties and oracle spot checks at both ends of the
+    buffer: tree(leaves) == tree(digests of the groups of four) == tree(forest roots); digests and forest roots against the oracle."""
+    import torch
+    import poseidon252_amd as P
+    import os
+    if log2n > 30 and os.environ.get("P252_TEST_HUGE") != "1":
+        pytest.skip("2^32 leaves (128 GiB): set P252_TEST_HUGE=1")
+    n = 1 << log2n
+    free, _ = torch.cuda.mem_get_info()
+    if free < int(1.8 * n * 32):
+        pytest.skip("needs %d GiB of free HBM" % (int(1.8 * n * 32) >> 30))
+    tag = oracle_mod.tag(0, [4], 1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(30)
+    d = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    for c in range(0, n, 1 << 27):  # (limbs below 2^62: every scalar is below p)
+        d[c:c + (1 << 27)] = torch.randint(0, 2 ** 62, (1 << 27, 4), dtype=torch.int64, device="cuda", generator=g)
+    root = P.merkle4_tree(d, tag=tag, ctx=gpu_ctx)
+    # level 1 on its own: 2^28 digests in one launch, 8 GiB of output
+    lvl1 = torch.empty((n // 4, 4), dtype=torch.int64, device="cuda")
+    gpu_ctx.hash_batch_device(tag, d, 4, 1, lvl1, n // 4)
+    assert torch.equal(P.merkle4_tree(lvl1, tag=tag, ctx=gpu_ctx), root)
+    idx = torch.tensor([0, 1, 12345, (n >> 3) + 5, (n >> 2) - 2, (n >> 2) - 1], device="cuda")  # incl. the last items: byte offsets > 2^35
+    got = lvl1[idx].cpu().numpy().view(np.uint64)
+    inp = d.view(n // 4, 4, 4)[idx].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, oracle_mod.hash_batch(tag, inp, 4, 1).reshape(-1, 4))
+    del lvl1
+    # the same leaves as a forest of 2^18 trees of 4^6 leaves (one launch per level across all trees)
+    per = 4 ** 6
+    roots = P.merkle4_forest(d, per, tag=tag, ctx=gpu_ctx)
+    assert roots.shape[0] == n // per and torch.equal(P.merkle4_tree(roots.contiguous(), tag=tag, ctx=gpu_ctx), root)
+    for t in (0, 77777, n // per - 1):
+        leaves_t = d[t * per:(t + 1) * per].cpu().numpy().view(np.uint64)
+        assert np.array_equal(roots[t].cpu().numpy().view(np.uint64), oracle_mod.merkle4_tree(tag, leaves_t)[0]), t
+    assert P.levels_len(n) == (4 ** (log2n // 2) - 1) // 3
+    del d, roots
+    torch.cuda.empty_cache()
