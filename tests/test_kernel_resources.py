@@ -13,15 +13,14 @@ CSRC = os.path.join(ROOT, "poseidon252_amd", "csrc")
 
 
 @pytest.fixture(scope="module")
-def isa(tmp_path_factory):
-    from poseidon252_amd import build as b
-    b._gen_assets()
-    out = tmp_path_factory.mktemp("isa") / "kernels.s"
-    cmd = [b._hipcc()] + [f for f in b.HIPCC_FLAGS if f != "-fPIC"] + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
-                                                                      "-o", str(out), os.path.join(CSRC, "kernels.hip")]
-    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
-    assert proc.returncode == 0, proc.stderr[-2000:]
-    return open(out).read(), proc.stderr
+def isa():
+    """(ISA text, resource-usage remarks) of kernels.hip — ONE ~55 s compile shared with tests/test_isa_counts.py through the cache of
+    tools/isa_count.compile_asm (keyed by the digest of the sources and flags)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_count as ic
+    out, remarks = ic.compile_asm(with_remarks=True)
+    return open(out).read(), remarks
 
 
 def test_no_scratch_and_register_budget(isa):

@@ -34,15 +34,35 @@ FOUR_CYCLE_PREFIXES = ("v_mad_i64_i32", "v_mad_u64_u32", "v_lshl_add_u64", "v_as
                        "v_fma_f64", "v_mov_b32_dpp")
 
 
-def compile_asm(extra_flags=()):
+def compile_asm(extra_flags=(), with_remarks=False):
+    """kernels.hip -> gfx950 ISA text (hipcc -S, the library's flags).  The compile takes ~55 s and two CPU tests want its output
+    (tests/test_isa_counts.py, tests/test_kernel_resources.py): the result is cached under the temp directory, keyed by the digest of
+    the sources and flags; the resource-usage remarks (-Rpass-analysis=kernel-resource-usage, stderr) are kept beside it.
+    with_remarks=True returns (asm_path, remarks_text)."""
+    import hashlib
     sys.path.insert(0, ROOT)
     from poseidon252_amd import build as b
     b._gen_assets()
-    out = os.path.join(tempfile.mkdtemp(prefix="p252_isa_"), "kernels.s")
-    cmd = [b._hipcc()] + [f for f in b.HIPCC_FLAGS if f != "-fPIC"] + list(extra_flags) + [
-        "-S", "--cuda-device-only", "-o", out, os.path.join(b.CSRC, "kernels.hip")]
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
-    return out
+    flags = [f for f in b.HIPCC_FLAGS if f != "-fPIC"] + list(extra_flags) + ["-Rpass-analysis=kernel-resource-usage"]
+    h = hashlib.sha256(" ".join([b._hipcc()] + flags).encode())
+    for f in sorted(os.listdir(b.CSRC)) + [os.path.join("_gen", "assets.inc")]:
+        path = os.path.join(b.CSRC, f)
+        if os.path.isfile(path) and f.endswith((".hip", ".hpp", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(path, "rb").read())
+    d = os.path.join(tempfile.gettempdir(), "p252_isa_cache_" + h.hexdigest()[:20])
+    out, rem = os.path.join(d, "kernels.s"), os.path.join(d, "remarks.txt")
+    if not (os.path.exists(out) and os.path.exists(rem)):
+        os.makedirs(d, exist_ok=True)
+        tmp = out + ".%d.tmp" % os.getpid()
+        cmd = [b._hipcc()] + flags + ["-S", "--cuda-device-only", "-o", tmp, os.path.join(b.CSRC, "kernels.hip")]
+        proc = subprocess.run(cmd, capture_output=True, text=True, cwd=b.CSRC)
+        if proc.returncode != 0:
+            raise SystemExit("hipcc -S kernels.hip failed:\n" + proc.stderr[-3000:])
+        open(rem + ".tmp", "w").write(proc.stderr)
+        os.replace(rem + ".tmp", rem)
+        os.replace(tmp, out)
+    return (out, open(rem).read()) if with_remarks else out
 
 
 def kernel_body(asm_text, name):
