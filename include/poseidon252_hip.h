@@ -39,7 +39,8 @@
  * streams of one context may overlap on the device: every root-only tree / forest build (d_levels == NULL) ping-pongs its
  * levels in scratch owned by the context PER STREAM (up to four streams at once; a fifth takes over the least recently used
  * scratch behind an event — never concurrently), and a communicator's buffers are handed from one stream to the next behind
- * an event as well.  The one context-wide piece of state is the encryption call table: p252_{encrypt,decrypt}_batch_device
+ * an event as well.  Memory: that scratch is grow-only and sized by the largest build of its stream — 5/16 of the leaves' bytes
+ * (160 MiB for 2^24 leaves, 40 GiB for 2^32) PER stream in use; pass d_levels to keep a build's memory entirely the caller's.  The one context-wide piece of state is the encryption call table: p252_{encrypt,decrypt}_batch_device
  * with another (variant, len) than the previous call drains the device before replacing it.
  * HIP graphs: the `*_device` hashing and tree entry points do nothing but enqueue kernels (and one 32-byte copy) on `hip_stream`, so
  * they can be stream-captured into a hipGraph and replayed on new data in the same buffers; call once outside the capture first
