@@ -345,6 +345,16 @@ inline void merkle4_forest_device(const void* d_leaves, std::size_t n_trees, std
                   "merkle4_forest_device");
 }
 
+// `Opening::verify` of the downstream poseidon-merkle consumer (AGENTS.md:62-66) for n device-resident arity-4 openings against ONE
+// root: d_ok[i] = 1 iff opening i re-hashes to *d_root (p252_merkle4_verify_batch_device); layouts as p252_merkle4_path_batch_device.
+inline void merkle4_verify_batch_device(const void* d_leaves, const void* d_siblings, const void* d_positions, std::size_t depth,
+                                        const void* d_root, void* d_ok, std::size_t n, Context& ctx = Context::default_context(),
+                                        void* stream = nullptr) {
+    const BlsScalar tag = compute_tag(Domain::Merkle4, {4}, 1);
+    detail::check(p252_merkle4_verify_batch_device(ctx.get(), tag.data(), d_leaves, d_siblings, d_positions, depth, d_root, d_ok, n, stream),
+                  ctx.get(), "merkle4_verify_batch_device");
+}
+
 // ---- dusk_poseidon::encrypt / decrypt (src/encryption.rs:62-95), batched; `variant` = P252_CRYPT_STREAM (default) or
 // P252_CRYPT_DUPLEX — the construction is UNPINNED.  secrets[i] = {shared.get_u(), shared.get_v()}. ----
 struct DecryptionFailed : std::runtime_error {  // dusk_poseidon::Error::DecryptionFailed (src/error.rs:27-29)

@@ -69,7 +69,7 @@ extern "C" {
  *      p252_merkle2_path_batch_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
  *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on)
  *   7  + p252_hash_batch_truncated[_device] (finalize_truncated fused into the digest kernels' output stage: one launch),
- *      p252_wipe, p252_scratch_residue; the host-buffer p252_{encrypt,decrypt}_batch and p252_destroy clear the library-owned
+ *      p252_wipe, p252_scratch_residue, p252_merkle{4,2}_verify_batch_device; the host-buffer p252_{encrypt,decrypt}_batch and p252_destroy clear the library-owned
  *      copies of what they were handed; root-only tree / forest builds on DIFFERENT streams of one context no longer share
  *      scratch; p252_merkle4_tree_multi_device accepts any array of contexts again (as ABI 5 did) and makes no communicator for
  *      a single context */
@@ -263,6 +263,15 @@ int p252_merkle2_openings_device(p252_ctx* ctx, const void* d_leaves, size_t n_l
                                  void* d_leaves_out, void* d_siblings, void* d_positions, void* d_n_bad, void* hip_stream);
 int p252_merkle2_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
                                    const void* d_positions, size_t depth, void* d_roots, size_t n, void* hip_stream);
+
+/* Opening::verify in bulk (the downstream poseidon-merkle verifier, AGENTS.md:62-66): the n openings are re-hashed exactly as
+ * p252_merkle{4,2}_path_batch_device does and each result is compared with the ONE expected root at d_root (32 bytes, device):
+ * d_ok[i] = 1 iff opening i leads to that root — n bytes leave the device instead of n x 32.  The recomputed roots live in the
+ * context's scratch of `hip_stream`.  Asynchronous. */
+int p252_merkle4_verify_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                     const void* d_positions, size_t depth, const void* d_root, void* d_ok, size_t n, void* hip_stream);
+int p252_merkle2_verify_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                     const void* d_positions, size_t depth, const void* d_root, void* d_ok, size_t n, void* hip_stream);
 
 /* A FOREST of n_trees independent complete arity-4 trees of leaves_per_tree = 4^k leaves each (the downstream poseidon-merkle
  * shape, AGENTS.md:62-66: many small trees), tree-major in d_leaves.  Level l of all trees is one array of

@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "p252_merkle4_tree_sharded_device", "p252_merkle4_tree_multi_device_resident", "p252_merkle4_forest_device", "p252_merkle2_forest_device", "p252_merkle4_forest", "p252_merkle4_openings_device", "p252_merkle4_depth",
     "p252_merkle2_openings_device", "p252_merkle2_depth", "p252_merkle2_path_batch_device",
     "p252_hash_batch_truncated", "p252_hash_batch_truncated_device", "p252_wipe", "p252_scratch_residue",
+    "p252_merkle4_verify_batch_device", "p252_merkle2_verify_batch_device",
 )
 ABI_VERSION = 7  # include/poseidon252_hip.h P252_ABI_VERSION this binding was written against
 
@@ -208,6 +209,8 @@ def lib():
     L.p252_merkle2_path_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
     L.p252_hash_batch_truncated.argtypes = [_vp, _u64p, _u64p, _sz, _sz, _u64p, _sz]
     L.p252_hash_batch_truncated_device.argtypes = [_vp, _u64p, _vp, _sz, _sz, _vp, _sz, _vp]
+    L.p252_merkle4_verify_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
+    L.p252_merkle2_verify_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
     L.p252_wipe.argtypes = [_vp]
     L.p252_scratch_residue.argtypes = [_vp, _u64p]
     L.p252_abi_version.restype = ctypes.c_int

@@ -1023,6 +1023,40 @@ int p252_merkle2_path_batch_device(p252_ctx* ctx, const uint64_t tag[4], const v
     return P252_OK;
 }
 
+// Opening::verify in bulk: re-hash (either arity) into this stream's scratch, then one byte per opening
+static int verify_batch_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                               const void* d_positions, size_t depth, const void* d_root, void* d_ok, size_t n, void* hip_stream) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    if (n == 0) return P252_OK;
+    const std::string who = arity == 4 ? "merkle4_verify" : "merkle2_verify";
+    if (!d_root || !d_ok) return fail(ctx, P252_ERR_INVALID_ARGUMENT, who + ": NULL buffer");
+    if (misaligned(d_root)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, ALIGN_MSG);
+    if (n > (SIZE_MAX / 32)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, who + ": size overflow");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    p252_ctx::LevelSet* set = nullptr;  // the recomputed roots live in the scratch pair of THIS stream (ctx.hpp): n x 32 bytes
+    int rc = level_set(ctx, st, n * 32, 0, &set);
+    if (rc) return rc;
+    rc = arity == 4 ? p252_merkle4_path_batch_device(ctx, tag, d_leaves, d_siblings, d_positions, depth, set->buf[0], n, hip_stream)
+                    : p252_merkle2_path_batch_device(ctx, tag, d_leaves, d_siblings, d_positions, depth, set->buf[0], n, hip_stream);
+    if (rc == P252_OK) {
+        const hipError_t e = launch_compare_roots(set->buf[0], d_root, d_ok, n, st);
+        if (e != hipSuccess) rc = fail(ctx, P252_ERR_HIP, who + ": " + hipGetErrorString(e));
+    }
+    const int rc2 = level_set_done(ctx, set);
+    return rc ? rc : rc2;
+}
+
+int p252_merkle4_verify_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                     const void* d_positions, size_t depth, const void* d_root, void* d_ok, size_t n, void* hip_stream) {
+    return verify_batch_device(ctx, 4, tag, d_leaves, d_siblings, d_positions, depth, d_root, d_ok, n, hip_stream);
+}
+
+int p252_merkle2_verify_batch_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, const void* d_siblings,
+                                     const void* d_positions, size_t depth, const void* d_root, void* d_ok, size_t n, void* hip_stream) {
+    return verify_batch_device(ctx, 2, tag, d_leaves, d_siblings, d_positions, depth, d_root, d_ok, n, hip_stream);
+}
+
 size_t p252_merkle2_depth(size_t n_leaves) {
     size_t d = 0;
     for (size_t c = n_leaves; c > 1; c = (c + 1) / 2) ++d;

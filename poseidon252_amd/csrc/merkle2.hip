@@ -67,4 +67,22 @@ hipError_t launch_merkle2_path(const int32_t* tab, const TagArg& tag, const void
     return hipGetLastError();
 }
 
+// ---- Opening::verify in bulk (the downstream poseidon-merkle verifier, AGENTS.md:62-66): the re-hashed roots of n openings against
+// the ONE expected root.  ok[i] = 1 iff equal — n bytes leave the device instead of n x 32.  Data movement only (32 B in, 1 B out per
+// opening), behind either arity's re-hash kernel. ----
+__global__ void __launch_bounds__(256) k_compare_roots(const uint4* __restrict__ roots, const uint4* __restrict__ expected, uint8_t* __restrict__ ok, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 e0 = expected[0], e1 = expected[1], a = roots[2 * i], b = roots[2 * i + 1];
+    const bool same = a.x == e0.x && a.y == e0.y && a.z == e0.z && a.w == e0.w && b.x == e1.x && b.y == e1.y && b.z == e1.z && b.w == e1.w;
+    ok[i] = same ? (uint8_t)1 : (uint8_t)0;
+}
+
+hipError_t launch_compare_roots(const void* roots, const void* expected, void* ok, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_compare_roots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const uint4*>(roots),
+                       static_cast<const uint4*>(expected), static_cast<uint8_t*>(ok), n);
+    return hipGetLastError();
+}
+
 }  // namespace p252

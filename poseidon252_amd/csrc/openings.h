@@ -24,4 +24,7 @@ struct TagArg;
 hipError_t launch_merkle2_path(const int32_t* tab, const TagArg& tag, const void* leaves, const void* siblings, const void* positions, unsigned depth,
                                void* roots, size_t n, hipStream_t st);
 
+// merkle2.hip: ok[i] = (roots[i] == *expected), one byte per opening (Opening::verify in bulk, behind either arity's re-hash)
+hipError_t launch_compare_roots(const void* roots, const void* expected, void* ok, size_t n, hipStream_t st);
+
 }  // namespace p252

@@ -360,6 +360,18 @@ class Context:
             self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), d_siblings.data_ptr() if depth else None,
             d_positions.data_ptr() if depth else None, depth, d_roots.data_ptr(), n, self._stream()))
 
+    def merkle_verify_batch_device(self, tag, d_leaves, d_siblings, d_positions, depth, d_root, d_ok, n, arity=4):
+        """`Opening::verify` in bulk (the downstream poseidon-merkle verifier, AGENTS.md:62-66): d_ok[i] (uint8) = 1 iff opening i
+        re-hashes to the ONE root at d_root — p252_merkle{4,2}_verify_batch_device; n bytes come back instead of n x 32"""
+        tag = _as_scalars(tag).reshape(4)
+        per = 3 if arity == 4 else 1
+        assert d_leaves.is_cuda and d_root.is_cuda and d_ok.is_cuda and self._nbytes(d_leaves) >= n * 32 and self._nbytes(d_root) >= 32 and self._nbytes(d_ok) >= n
+        if depth:
+            assert self._nbytes(d_siblings) >= n * depth * per * 32 and self._nbytes(d_positions) >= n * depth
+        fn = _lib.lib().p252_merkle4_verify_batch_device if arity == 4 else _lib.lib().p252_merkle2_verify_batch_device
+        self._check(fn(self._h, tag.ctypes.data_as(_u64p), d_leaves.data_ptr(), d_siblings.data_ptr() if depth else None,
+                       d_positions.data_ptr() if depth else None, depth, d_root.data_ptr(), d_ok.data_ptr(), n, self._stream()))
+
     # ---- measurement aid: the shader clock (bench.py) ----
     def clock_probe(self, spin_us=1000, stream=None):
         """launches the one-wave clock probe (p252_clock_probe_device) on `stream` (a torch.cuda.Stream; default: the current

@@ -299,3 +299,60 @@ def test_device_entry_points_capture_into_a_hip_graph(gpu_ctx, oracle_mod):
         assert np.array_equal(_host(o_sp).reshape(n_sp, 5, 4)[idx], oracle_mod.hash_batch(hb5.tag, np.ascontiguousarray(sp[idx]), 42, 5, threads=8)), rep
         e_root, e_levels, _ = oracle_mod.merkle4_tree(tag4, lv, want_levels=True)
         assert np.array_equal(_host(o_root), e_root) and np.array_equal(_host(o_levels), e_levels) and np.array_equal(_host(o_root2), e_root), rep
+
+
+# ---------------------------------------------------------------------------------------------- Opening::verify in bulk
+@pytest.mark.parametrize("arity,n_leaves,k", [(4, 4 ** 7, 20000), (4, 5001, 3000), (2, 2 ** 12, 5000), (2, 70001, 20000), (4, 1, 3)])
+def test_verify_batch_flags_exactly_the_tampered_openings(gpu_ctx, oracle_mod, arity, n_leaves, k):
+    """p252_merkle{4,2}_verify_batch_device — `Opening::verify` of the downstream poseidon-merkle consumer (AGENTS.md:62-66) for k openings
+    against ONE root: build (all levels) -> extract -> tamper with a known subset (a sibling limb, the leaf, a position byte) -> verify,
+    all on the device.  The flags are exactly the untouched openings; the oracle's re-hash of a sample agrees opening by opening; and
+    the call on two streams of one context at once gives the same flags (the recomputed roots live in per-stream scratch)."""
+    import torch
+    import poseidon252_amd as P
+    tag = P.merkle4_tag() if arity == 4 else P.compute_tag(P.Domain.Merkle2, [2], 1)
+    lv = oracle_mod.fill_random(0xe0 + n_leaves + arity, n_leaves)
+    root, levels = (gpu_ctx.merkle4_tree if arity == 4 else gpu_ctx.merkle2_tree)(tag, lv, want_levels=True)
+    assert np.array_equal(root, (oracle_mod.merkle4_tree if arity == 4 else oracle_mod.merkle2_tree)(tag, lv)[0])
+    d_lv = _dev(lv)
+    d_levels = _dev(levels if levels.shape[0] else np.zeros((1, 4), dtype=np.uint64))
+    d_root = _dev(root)
+    rng = np.random.default_rng(n_leaves + arity)
+    idx = rng.integers(0, n_leaves, size=k).astype(np.int32)
+    out, sib, pos, depth = gpu_ctx.merkle4_openings_device(d_lv, n_leaves, d_levels, torch.from_numpy(idx).to("cuda:0"), k, check=True, arity=arity)
+    ok = torch.zeros(k, dtype=torch.uint8, device="cuda:0")
+    gpu_ctx.merkle_verify_batch_device(tag, out, sib, pos, depth, d_root, ok, k, arity=arity)
+    torch.cuda.synchronize()
+    assert bool(ok.all()), "an untouched opening of the tree does not verify"
+    # tamper: every 7th opening, by one of three means
+    bad = np.arange(0, k, 7)
+    h_out, h_sib, h_pos = out.cpu().numpy().copy(), sib.cpu().numpy().copy(), pos.cpu().numpy().copy()
+    for j, i in enumerate(bad):
+        kind = j % 3 if depth else 1
+        if kind == 0:
+            h_sib.reshape(k, -1)[i, (j * 5) % h_sib.reshape(k, -1).shape[1]] ^= 1  # one bit of one limb of one sibling
+        elif kind == 1:
+            h_out[i, 0] ^= 1 << 7  # the leaf
+        else:
+            h_pos[i, j % depth] ^= 1  # the path turns the other way at one level
+    t_out, t_sib, t_pos = torch.from_numpy(h_out).to("cuda:0"), torch.from_numpy(h_sib).to("cuda:0"), torch.from_numpy(h_pos).to("cuda:0")
+    ok2 = torch.ones(k, dtype=torch.uint8, device="cuda:0")
+    ok3 = torch.ones(k, dtype=torch.uint8, device="cuda:0")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        gpu_ctx.merkle_verify_batch_device(tag, t_out, t_sib, t_pos, depth, d_root, ok2, k, arity=arity)
+    with torch.cuda.stream(s2):  # (the untouched arrays on a second stream at the same time: all ones)
+        gpu_ctx.merkle_verify_batch_device(tag, out, sib, pos, depth, d_root, ok3, k, arity=arity)
+    torch.cuda.synchronize()
+    expect = np.ones(k, dtype=np.uint8)
+    expect[bad] = 0
+    got = ok2.cpu().numpy()
+    # (a flipped position bit whose sibling equals the path's node would still verify: cannot happen with random leaves)
+    assert np.array_equal(got, expect), (np.nonzero(got != expect)[0][:10], depth)
+    assert bool(ok3.all())
+    if arity == 4 and depth:  # the oracle re-hashes a sample of the tampered openings: equal to the root exactly where the flag is set
+        sample = np.arange(0, k, max(1, k // 60))
+        o_roots = oracle_mod.merkle4_path_batch(tag, np.ascontiguousarray(h_out.view(np.uint64)[sample]),
+                                                np.ascontiguousarray(h_sib.view(np.uint64).reshape(k, depth, 3, 4)[sample]), np.ascontiguousarray(h_pos[sample]))
+        assert np.array_equal((o_roots == root.reshape(1, 4)).all(axis=1).astype(np.uint8), got[sample])
