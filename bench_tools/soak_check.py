@@ -50,7 +50,7 @@ if "--long" in sys.argv:
     minutes = float(sys.argv[sys.argv.index("--long") + 1]) if len(sys.argv) > sys.argv.index("--long") + 1 else 5.0
     counts = {"permute": 0, "sponge": 0, "digest": 0, "tree leaves": 0, "openings": 0, "encrypt+decrypt": 0, "truncate": 0, "bytes": 0, "tree updates": 0,
               "forest trees": 0, "sharded-tree leaves (RCCL, one rank)": 0,
-              "openings extracted on the device": 0, "fused truncated outputs": 0, "root-only builds on concurrent streams": 0}
+              "openings extracted on the device": 0, "fused truncated outputs": 0, "root-only builds on concurrent streams": 0, "openings verified in bulk": 0}
     from poseidon252_amd import comm as C
     comm_ctx = P.Context(0)
     comm1 = C.Comm.create_rank(comm_ctx, 0, 1, lambda b: b)  # the library's RCCL communicator on the real backend (round 4)
@@ -61,7 +61,7 @@ if "--long" in sys.argv:
     while time.time() - t0 < 60 * minutes:
         it += 1
         seed = int(rng.integers(1, 1 << 30))
-        kind = it % 14
+        kind = it % 15
         n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 8193)), int(rng.integers(8193, 20000))]))
         if kind == 0:
             n = min(n, 12000)
@@ -215,6 +215,27 @@ if "--long" in sys.argv:
             for j in range(k):
                 assert np.array_equal(got[j], oracle.merkle4_tree(mtag, lvs[j])[0]), ("streams", sizes, j, seed)
             counts["root-only builds on concurrent streams"] += 3 * k
+        elif kind == 14:  # round 5: Opening::verify in bulk — extract, tamper a random subset, verify against the root, both arities
+            import torch
+            arity = int(rng.choice([4, 2]))
+            leaves_n = int(rng.choice([int(rng.integers(1, 3000)), arity ** int(rng.integers(0, 9 if arity == 4 else 15)), int(rng.integers(3000, 60000))]))
+            k = int(rng.integers(1, 6000))
+            vtag = mtag if arity == 4 else tag2
+            lv = oracle.fill_random(seed, leaves_n)
+            root, levels = (ctx.merkle4_tree if arity == 4 else ctx.merkle2_tree)(vtag, lv, want_levels=True)
+            assert np.array_equal(root, (oracle.merkle4_tree if arity == 4 else oracle.merkle2_tree)(vtag, lv)[0]), ("verify tree", arity, leaves_n, seed)
+            d_lv = torch.from_numpy(lv.view(np.int64).copy()).cuda()
+            d_levels = torch.from_numpy(np.ascontiguousarray(levels if levels.shape[0] else np.zeros((1, 4), dtype=np.uint64)).view(np.int64)).cuda()
+            idx = rng.integers(0, leaves_n, size=k).astype(np.int32)
+            out, sib, pos, depth = ctx.merkle4_openings_device(d_lv, leaves_n, d_levels, torch.from_numpy(idx).cuda(), k, check=True, arity=arity)
+            bad = rng.random(k) < 0.3
+            h_out = out.cpu().numpy().copy()
+            h_out[bad, int(rng.integers(0, 4))] ^= 1 << int(rng.integers(0, 60))  # the leaf of every tampered opening
+            ok = torch.zeros(k, dtype=torch.uint8, device="cuda")
+            ctx.merkle_verify_batch_device(vtag, torch.from_numpy(h_out).cuda(), sib, pos, depth, torch.from_numpy(root.view(np.int64).copy()).cuda(), ok, k, arity=arity)
+            torch.cuda.synchronize()
+            assert np.array_equal(ok.cpu().numpy().astype(bool), ~bad), ("verify", arity, leaves_n, k, seed)
+            counts["openings verified in bulk"] += k
         elif kind == 10:  # subtree -> ncclAllGather of the roots on the stream -> top levels, inside the library
             import torch
             leaves_n = 4 ** int(rng.integers(0, 10))
