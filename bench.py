@@ -82,7 +82,7 @@ def kernel_sources_sha256(kernel=None):
     """digest of the sources `kernel` is compiled from: the hashing kernels' files; the extraction kernel's own file on top for it
     (a change of csrc/openings.hip makes only ITS counter passes stale)"""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES + (("openings.hip",) if kernel and "openings" in kernel else ()):
+    for f in KERNEL_SOURCES + (("openings.hip", "fastdiv.hpp") if kernel and "openings" in kernel else ()):
         h.update(open(os.path.join(ROOT, "poseidon252_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -86,6 +86,8 @@ class Context {
     // clears every scratch buffer the context owns (zeroize, Cargo.toml:14); the host-buffer encrypt / decrypt calls and the
     // destructor do so themselves
     void wipe() { detail::check(p252_wipe(ctx_.get()), ctx_.get(), "Context::wipe"); }
+    // gives the grow-only scratch back (waits for the device, wipes, frees); the next call allocates what it needs again
+    void trim() { detail::check(p252_trim(ctx_.get()), ctx_.get(), "Context::trim"); }
     static Context& default_context() {
         static Context c(0);
         return c;

@@ -44,7 +44,13 @@
  * with another (variant, len) than the previous call drains the device before replacing it.
  * HIP graphs: the `*_device` hashing and tree entry points do nothing but enqueue kernels (and one 32-byte copy) on `hip_stream`, so
  * they can be stream-captured into a hipGraph and replayed on new data in the same buffers; call once outside the capture first
- * (context-owned scratch and the encryption call table are allocated / uploaded on first use, which a capture cannot do).  Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
+ * (context-owned scratch and the encryption call table are allocated / uploaded on first use, which a capture cannot do).
+ * A tree / forest / verify build that is CAPTURED should pass caller-owned scratch (d_levels; for verify: re-hash into a buffer of
+ * the caller's with p252_merkle{4,2}_path_batch_device): with d_levels = NULL the graph holds the addresses of the context's
+ * per-stream pair and the pair's hand-over event becomes a graph node, so a replay is ordered against nothing the context does
+ * later — a fifth stream taking the pair over, p252_trim, a growing build — and would race with it.  The hashing
+ * entry points (digests, sponges, permutations, truncated forms) use no context scratch and capture without conditions.
+ * Multi-GPU = one context per GPU: either one process (or thread) per GPU driving its own context,
  * or the p252_*_multi entry points below, which take the array of contexts and shard inside the library; batches
  * shard with no inter-GPU dependence.
  */
@@ -72,8 +78,14 @@ extern "C" {
  *      p252_wipe, p252_scratch_residue, p252_merkle{4,2}_verify_batch_device; the host-buffer p252_{encrypt,decrypt}_batch and p252_destroy clear the library-owned
  *      copies of what they were handed; root-only tree / forest builds on DIFFERENT streams of one context no longer share
  *      scratch; p252_merkle4_tree_multi_device accepts any array of contexts again (as ABI 5 did) and makes no communicator for
- *      a single context */
-#define P252_ABI_VERSION 7
+ *      a single context
+ *   8  RCCL is no longer a load-time dependency: the library resolves it on the first p252_comm_* / RCCL-path call (search
+ *      order: $P252_RCCL_PATH, a copy the process already holds, the loader's path, $ROCM_PATH/lib), so a single-GPU hashing
+ *      deployment needs no RCCL and a process gets ONE copy; + p252_comm_backend (which copy), p252_comm_check (a peer's failed
+ *      local build in a sharded tree: the healthy ranks' root becomes all-ones and p252_comm_check / p252_sync return
+ *      P252_ERR_COMM — they used to return a garbage root as P252_OK), p252_trim (gives the grow-only scratch back);
+ *      p252_scratch_residue no longer counts the encryption call table (it holds nothing of the caller's) */
+#define P252_ABI_VERSION 8
 
 #define P252_OK 0
 #define P252_ERR_IO_PATTERN_VIOLATION (-1) /* dusk_poseidon::Error::IOPatternViolation, src/error.rs:12-14 */
@@ -165,6 +177,8 @@ int p252_merkle4_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d
                              void* d_root, void* d_levels, void* hip_stream);
 int p252_merkle2_tree_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_leaves,
                              void* d_root, void* d_levels, void* hip_stream);
+/* waits for hip_stream.  P252_ERR_COMM when a sharded tree build of this context's communicator found a failed peer since the
+ * last call (see p252_comm_check). */
 int p252_sync(p252_ctx* ctx, void* hip_stream);
 /* Secret hygiene (the reference builds with `zeroize`, Cargo.toml:14; dusk-safe zeroizes a finished sponge).  The kernels keep
  * sponge states in registers only.  What a HOST-buffer call leaves behind is the library's copy of the caller's arrays — the
@@ -173,9 +187,17 @@ int p252_sync(p252_ctx* ctx, void* hip_stream);
  * demand (it waits for the device first; hashing calls do not wipe — their inputs are public).  `_device` callers own their
  * buffers; the only thing such a call leaves in the context is the (variant, len) call table, which holds no secret. */
 int p252_wipe(p252_ctx* ctx);
-/* diagnostics: the number of non-zero bytes in every scratch buffer the context owns (device scratch, level scratch, the
- * encryption call table, staging lanes on both sides) — 0 right after p252_wipe or a host-buffer encrypt / decrypt call */
+/* diagnostics: the number of non-zero bytes in every buffer of the context that receives caller data (device scratch, level
+ * scratch, staging lanes on both sides; not the encryption call table) — 0 right after p252_wipe, p252_trim or a host-buffer
+ * encrypt / decrypt call on a context that has done nothing else since its last wipe */
 int p252_scratch_residue(p252_ctx* ctx, uint64_t* nonzero_bytes);
+/* The context's scratch is grow-only (device scratch of the host-buffer entry points, up to four per-stream level pairs of
+ * 5/16 of a root-only build's leaves each, staging lanes, the call table): p252_trim waits for the device, clears it as p252_wipe
+ * does and FREES it — the reference holds no state at all (hash.rs:92-96).  The next call allocates what it needs again.  The
+ * constant table and a communicator stay.  Not to be called while a hipGraph captured from this context's root-only builds is
+ * still to be replayed: captured builds that pass d_levels = NULL bake the scratch addresses in (pass caller-owned d_levels to
+ * builds that are captured, which is also what keeps a replay from racing with another stream's build on the same pair). */
+int p252_trim(p252_ctx* ctx);
 
 /* ---- SURVEY §8(f) "next" rows ---- */
 /* finalize_truncated's post-processing (hash.rs:164-183) on n device-resident BlsScalars: canonical
@@ -343,15 +365,24 @@ int p252_merkle4_tree_multi_device_resident(p252_ctx* const* ctxs, size_t n_ctx,
  * only.  Creation and the sharded build are COLLECTIVE: every rank calls them, in the same order.  Every device allocation
  * of a rank happens before its first collective, so a rank that cannot allocate fails before its peers wait for it; a rank
  * whose subtree build fails later still enters the all-gather (contributing an all-ones root, which is no BlsScalar) and
- * returns its error — peers are never left blocked on the stream, and the job must treat one rank's error as the failure of
- * the build, as with any collective.  Builds of one communicator queued on different streams run one after the other
- * (event-ordered on the device), never concurrently. ---- */
+ * returns its error — peers are never left blocked on the stream.  The healthy ranks DETECT the sentinel on the device: their
+ * d_root is overwritten with all-ones as well, and the next p252_comm_check / p252_sync on that rank returns P252_ERR_COMM
+ * naming the failed rank (the build itself is asynchronous and has long returned P252_OK by then).  Builds of one communicator
+ * queued on different streams run one after the other (event-ordered on the device), never concurrently.
+ * RCCL is resolved at run time (ABI 8): without it these entry points return P252_ERR_COMM and p252_last_error lists what was
+ * tried; nothing else in this header needs it. ---- */
 int p252_comm_unique_id(void* id_out, size_t len /* = P252_COMM_ID_BYTES */);
 int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, int world, p252_comm** out);
 int p252_comm_create_all(p252_ctx* const* ctxs, size_t n_ctx, p252_comm** comms_out /* [n_ctx] */);
 void p252_comm_destroy(p252_comm* comm);
 int p252_comm_rank(const p252_comm* comm);
 int p252_comm_size(const p252_comm* comm);
+/* waits for hip_stream, then reports whether a sharded build of this communicator met a failed peer since the last check:
+ * P252_ERR_COMM (p252_last_error names the rank) once, P252_OK otherwise */
+int p252_comm_check(p252_comm* comm, void* hip_stream);
+/* which RCCL this process's library calls go to: resolves it if no call has yet, writes the path of the object the symbols
+ * came from (NUL-terminated, truncated to len; path_out may be NULL).  P252_ERR_COMM: none found (p252_last_error(NULL)) */
+int p252_comm_backend(char* path_out, size_t len);
 /* BASELINE configs[4], one rank's part (one process per GPU): this rank's n_leaves_local = 4^k device-resident leaves are
  * reduced to their root with zero communication, the `world` roots are all-gathered (the path's only exchange step, on
  * hip_stream) and the <= log4(world) + 1 top levels (zero-padded per hash.rs:22-26) are hashed on every rank: d_root

@@ -38,8 +38,9 @@ ABI_SYMBOLS = (
     "p252_merkle2_openings_device", "p252_merkle2_depth", "p252_merkle2_path_batch_device",
     "p252_hash_batch_truncated", "p252_hash_batch_truncated_device", "p252_wipe", "p252_scratch_residue",
     "p252_merkle4_verify_batch_device", "p252_merkle2_verify_batch_device",
+    "p252_trim", "p252_comm_check", "p252_comm_backend",
 )
-ABI_VERSION = 7  # include/poseidon252_hip.h P252_ABI_VERSION this binding was written against
+ABI_VERSION = 8  # include/poseidon252_hip.h P252_ABI_VERSION this binding was written against
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _szp = ctypes.POINTER(ctypes.c_size_t)
@@ -77,17 +78,34 @@ def _preload_torch_hip_runtime():
         ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     except OSError:
         return None
-    # the same for RCCL (the library links librccl.so.1 since ABI 6; torch bundles a copy under that SONAME): one copy per
-    # process.  NOT with RTLD_GLOBAL: a globally visible librccl ahead of `import torch` makes the process abort at exit
-    # ("double free or corruption": tests/test_gpu_parity.py::test_library_loaded_before_torch_leaves_torch_usable);
-    # a local load is enough — the loader satisfies the library's NEEDED entry from any loaded object of that SONAME
-    rccl = os.path.join(os.path.dirname(path), "librccl.so")
+    # (RCCL needs no such care since ABI 8: the library does not link it and, on its first communicator call, takes the copy the
+    # process already holds — torch's, once torch is imported — csrc/rccl_dyn.hpp)
+    return path
+
+
+def prefer_torch_rccl():
+    """Called by the communicator wrappers (comm.py, multi.py) before their first call.  The library resolves RCCL on first use and
+    takes a copy the process already holds (csrc/rccl_dyn.hpp) — after `import torch` that is torch's bundled one.  BEFORE torch is
+    imported it would load the system copy, and a later `import torch` would then be served that copy under the same SONAME instead of
+    the one it was built against; so when torch is installed but not yet imported, map its librccl first (locally, NOT RTLD_GLOBAL:
+    a globally visible librccl ahead of `import torch` makes the process abort at exit, tests/test_comm_forest.py).  C and Rust
+    callers need none of this: they have one RCCL, the one the resolver finds.  P252_RCCL_PATH / P252_SYSTEM_HIP_RUNTIME=1 opt out."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("P252_RCCL_PATH") or os.environ.get("P252_SYSTEM_HIP_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    rccl = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
     if os.path.exists(rccl):
         try:
             ctypes.CDLL(rccl)
         except OSError:
             pass
-    return path
 
 
 def lib():
@@ -212,6 +230,9 @@ def lib():
     L.p252_merkle4_verify_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
     L.p252_merkle2_verify_batch_device.argtypes = [_vp, _u64p, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]
     L.p252_wipe.argtypes = [_vp]
+    L.p252_trim.argtypes = [_vp]
+    L.p252_comm_check.argtypes = [_vp, _vp]
+    L.p252_comm_backend.argtypes = [ctypes.c_char_p, _sz]
     L.p252_scratch_residue.argtypes = [_vp, _u64p]
     L.p252_abi_version.restype = ctypes.c_int
     for name in ABI_SYMBOLS:

@@ -15,12 +15,14 @@ HIPCC_FLAGS = [
     # silently turns them into scratch-indexed loops
     "-mllvm", "-pragma-unroll-threshold=1000000",
 ]
-SOURCES = ["kernels.hip", "openings.hip", "merkle2.hip", "api.cpp", "comm.cpp"]
-# comm.cpp: the RCCL communicator of the multi-GPU entry points (ncclBroadcast of the constants, ncclAllGather of subtree roots)
+SOURCES = ["kernels.hip", "openings.hip", "merkle2.hip", "api.cpp", "comm.cpp", "rccl_dyn.cpp"]
+# comm.cpp: the RCCL communicator of the multi-GPU entry points (ncclBroadcast of the constants, ncclAllGather of subtree roots).
+# RCCL is NOT linked: rccl_dyn.cpp resolves it with dlopen on first use (a hashing-only deployment needs no RCCL, and a
+# process that already holds a copy — torch's — gets that one); only its header is needed at build time.
 # (ROCM_PATH / HIP_PATH name the ROCm prefix when it is not /opt/rocm — ADVICE r4)
 ROCM = os.environ.get("ROCM_PATH") or os.environ.get("HIP_PATH") or "/opt/rocm"
-LINK_FLAGS = ["-L" + os.path.join(ROCM, "lib"), "-lrccl"]
-HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp", "ctx.hpp", "openings.h",
+LINK_FLAGS = ["-ldl"]
+HEADERS = ["fr29.hpp", "fr_host.hpp", "hades29.hpp", "coop29.hpp", "tables.hpp", "kernels.h", "blake2b.hpp", "ctx.hpp", "openings.h", "fastdiv.hpp", "rccl_dyn.hpp",
            os.path.join("..", "..", "include", "poseidon252_hip.h")]
 
 

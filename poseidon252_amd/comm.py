@@ -16,11 +16,22 @@ from .hash import _as_scalars, _raise
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 
 
+def backend():
+    """path of the RCCL the library's calls go to in this process (p252_comm_backend; resolves it if nothing has yet)"""
+    _lib.prefer_torch_rccl()
+    buf = ctypes.create_string_buffer(4096)
+    rc = _lib.lib().p252_comm_backend(buf, len(buf))
+    if rc:
+        _raise(rc, None, global_err=True)
+    return buf.value.decode()
+
+
 def unique_id():
+    _lib.prefer_torch_rccl()
     buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
     rc = _lib.lib().p252_comm_unique_id(buf, _lib.COMM_ID_BYTES)
     if rc:
-        _raise(rc, None)
+        _raise(rc, None, global_err=True)
     return buf.raw
 
 
@@ -50,6 +61,7 @@ class Comm:
         id_bytes = exchange(unique_id() if rank == 0 else None)
         assert len(id_bytes) == _lib.COMM_ID_BYTES
         h = ctypes.c_void_p()
+        _lib.prefer_torch_rccl()
         rc = _lib.lib().p252_comm_create_rank(ctx._h, id_bytes, _lib.COMM_ID_BYTES, rank, world, ctypes.byref(h))
         if rc:
             _raise(rc, ctx._h)
@@ -60,6 +72,7 @@ class Comm:
         k = len(ctxs)
         arr = (ctypes.c_void_p * k)(*[c._h for c in ctxs])
         out = (ctypes.c_void_p * k)()
+        _lib.prefer_torch_rccl()
         rc = _lib.lib().p252_comm_create_all(arr, k, out)
         if rc:
             _raise(rc, ctxs[0]._h)
@@ -84,6 +97,15 @@ class Comm:
         if rc:
             _raise(rc, self.ctx._h)
 
+    def check(self):
+        """wait for the current torch stream, then raise DeviceError if a sharded build of this communicator met a failed peer since
+        the last check (p252_comm_check): such a build's root is all-ones on every healthy rank"""
+        import torch
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = _lib.lib().p252_comm_check(self._h, st)
+        if rc:
+            _raise(rc, self.ctx._h)
+
     def destroy(self):
         if self._h:
             _lib.lib().p252_comm_destroy(self._h)
@@ -104,6 +126,7 @@ def merkle4_tree_multi_device_resident(ctxs, tag, d_leaves, leaves_per_ctx, d_ro
     arr = (ctypes.c_void_p * k)(*[c._h for c in ctxs])
     ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in d_leaves])
     outs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in d_roots])
+    _lib.prefer_torch_rccl()
     rc = _lib.lib().p252_merkle4_tree_multi_device_resident(arr, k, tag.ctypes.data_as(_u64p), ptrs, leaves_per_ctx, outs, None)
     if rc:
         _raise(rc, ctxs[0]._h)

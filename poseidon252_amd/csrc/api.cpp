@@ -57,7 +57,11 @@ int p252host::level_set(p252_ctx* ctx, hipStream_t st, size_t need0, size_t need
         ctx->lvl.emplace_back();
         set = &ctx->lvl.back();
         set->st = st;
-        HIP_TRY(ctx, hipEventCreateWithFlags(&set->done, hipEventDisableTiming));
+        const hipError_t e = hipEventCreateWithFlags(&set->done, hipEventDisableTiming);
+        if (e != hipSuccess) {  // never leave a half-made pair (done == nullptr) in the list
+            ctx->lvl.pop_back();
+            return fail(ctx, P252_ERR_HIP, std::string("hipEventCreateWithFlags: ") + hipGetErrorString(e));
+        }
     }
     if (!set) {  // more streams than pairs: take over the least recently used pair, behind its last build
         set = &ctx->lvl[0];
@@ -79,6 +83,28 @@ int p252host::level_set_done(p252_ctx* ctx, p252_ctx::LevelSet* set) {
     HIP_TRY(ctx, hipEventRecord(set->done, set->st));
     return P252_OK;
 }
+
+namespace {
+// Records the pair's event on EVERY way out of a builder — also when a launch failed half way: the launches before it are queued and
+// touch the pair, and a later takeover by another stream waits on this event (the early returns used to skip it and
+// left the event of an OLDER build for the next takeover).  finish() on the success path returns the record's own status.
+struct LevelSetGuard {
+    p252_ctx* ctx;
+    p252_ctx::LevelSet* set = nullptr;
+    explicit LevelSetGuard(p252_ctx* c) : ctx(c) {}
+    int finish() {
+        p252_ctx::LevelSet* s = set;
+        set = nullptr;
+        return s ? p252host::level_set_done(ctx, s) : P252_OK;
+    }
+    ~LevelSetGuard() {
+        if (!set) return;
+        const std::string msg = ctx->err;  // (the failure being reported stays the message)
+        (void)p252host::level_set_done(ctx, set);
+        ctx->err = msg;
+    }
+};
+}  // namespace
 
 const std::vector<int32_t>& p252host::host_tables() {
     static const std::vector<int32_t> tab = [] {
@@ -127,15 +153,19 @@ static int for_each_ctx(p252_ctx* const* ctxs, size_t n_ctx, F&& f) {
 // those at the end of such a call; wipe_all clears every buffer the context owns (p252_wipe, p252_destroy). ----
 static hipError_t wipe_span(void* d, size_t bytes) { return (d && bytes) ? hipMemsetAsync(d, 0, bytes, nullptr) : hipSuccess; }
 
-static hipError_t wipe_lanes(p252_ctx* ctx) {
+// dirty_only: just the bytes calls may have written since the last wipe (staged_run keeps the extent per slot) — what the per-call
+// wipe of a host-buffer encrypt / decrypt needs; the full capacity otherwise (p252_wipe, p252_trim, p252_destroy)
+static hipError_t wipe_lanes(p252_ctx* ctx, bool dirty_only = false) {
     hipError_t first = hipSuccess;
     for (auto& l : ctx->lanes)
         for (auto& sl : l.slot) {
-            if (sl.h_in) std::memset(sl.h_in, 0, sl.in_cap);
-            if (sl.h_out) std::memset(sl.h_out, 0, sl.out_cap);
-            hipError_t e = wipe_span(sl.d_in, sl.in_cap);
-            if (e == hipSuccess) e = wipe_span(sl.d_out, sl.out_cap);
+            const size_t in_b = dirty_only ? sl.in_dirty : sl.in_cap, out_b = dirty_only ? sl.out_dirty : sl.out_cap;
+            if (sl.h_in && in_b) std::memset(sl.h_in, 0, in_b);
+            if (sl.h_out && out_b) std::memset(sl.h_out, 0, out_b);
+            hipError_t e = wipe_span(sl.d_in, in_b);
+            if (e == hipSuccess) e = wipe_span(sl.d_out, out_b);
             if (e != hipSuccess && first == hipSuccess) first = e;
+            sl.in_dirty = sl.out_dirty = 0;
         }
     return first;
 }
@@ -176,7 +206,7 @@ extern "C" {
 
 int p252_abi_version(void) { return P252_ABI_VERSION; }
 
-const char* p252_version(void) { return "poseidon252_hip 0.7 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
+const char* p252_version(void) { return "poseidon252_hip 0.8 (gfx950; 9x29-bit limbs; integer MDS + integer ARMA recurrence; 32-bit Montgomery quotient digits; lane-group kernels for small batches)"; }
 
 int p252_device_count(void) {
     int n = 0;
@@ -214,22 +244,24 @@ int p252_create(int device_id, p252_ctx** out) {
     return P252_OK;
 }
 
-void p252_destroy(p252_ctx* ctx) {
-    if (!ctx) return;
-    release_ctx_comm(ctx);
-    (void)hipSetDevice(ctx->device);
-    (void)wipe_all(ctx);  // nothing a call left in the context's scratch or staging survives it (zeroize, Cargo.toml:14)
-    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+// gives back what the grow-only scratch has grown to (after a 2^32-leaf root-only build the context kept 40 GiB
+// until p252_destroy).  Wiped first, like p252_wipe; the constant table, the communicator and its 100 bytes stay.
+static void free_scratch(p252_ctx* ctx) {
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_in = ctx->d_out = nullptr;
+    ctx->d_in_cap = ctx->d_out_cap = 0;
     for (auto& s : ctx->lvl) {
         for (int i = 0; i < 2; ++i)
             if (s.buf[i]) (void)hipFree(s.buf[i]);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    for (int i = 0; i < 3; ++i)
-        if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
+    ctx->lvl.clear();
     if (ctx->d_prog) (void)hipFree(ctx->d_prog);
+    ctx->d_prog = nullptr;
+    ctx->d_prog_cap = 0;
+    ctx->prog_variant = -1;
+    ctx->prog_len = 0;
     for (auto& l : ctx->lanes) {
         if (l.st) (void)hipStreamDestroy(l.st);
         for (auto& sl : l.slot) {
@@ -240,6 +272,18 @@ void p252_destroy(p252_ctx* ctx) {
             if (sl.done) (void)hipEventDestroy(sl.done);
         }
     }
+    ctx->lanes.clear();
+}
+
+void p252_destroy(p252_ctx* ctx) {
+    if (!ctx) return;
+    release_ctx_comm(ctx);
+    (void)hipSetDevice(ctx->device);
+    (void)wipe_all(ctx);  // nothing a call left in the context's scratch or staging survives it (zeroize, Cargo.toml:14)
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    free_scratch(ctx);
+    for (int i = 0; i < 3; ++i)
+        if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
     delete ctx;
 }
 
@@ -253,6 +297,14 @@ int p252_sync(p252_ctx* ctx, void* hip_stream) {
     if (!ctx) return P252_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+    return comm_take_failure(ctx);  // a peer's failed local build in a sharded tree on this stream surfaces here (comm.cpp)
+}
+
+int p252_trim(p252_ctx* ctx) {
+    if (!ctx) return P252_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, wipe_all(ctx));  // (starts with a device synchronisation: nothing queued still uses what is freed below)
+    free_scratch(ctx);
     return P252_OK;
 }
 
@@ -272,7 +324,7 @@ int p252_scratch_residue(p252_ctx* ctx, uint64_t* nonzero_bytes) {
     HIP_TRY(ctx, count_nonzero_device(ctx->d_out, ctx->d_out_cap, nonzero_bytes));
     for (auto& set : ctx->lvl)
         for (int i = 0; i < 2; ++i) HIP_TRY(ctx, count_nonzero_device(set.buf[i], set.cap[i], nonzero_bytes));
-    HIP_TRY(ctx, count_nonzero_device(ctx->d_prog, ctx->d_prog_cap, nonzero_bytes));
+    // (d_prog, the sponge-call table of the last (variant, length), holds nothing of the caller's: not counted)
     for (auto& l : ctx->lanes)
         for (auto& sl : l.slot) {
             HIP_TRY(ctx, count_nonzero_device(sl.d_in, sl.in_cap, nonzero_bytes));
@@ -354,7 +406,8 @@ int p252host::merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t t
     const char* cur = static_cast<const char*>(d_leaves);
     size_t cur_n = n_leaves;
     char* lv = static_cast<char*>(d_levels);
-    p252_ctx::LevelSet* set = nullptr;
+    LevelSetGuard guard(ctx);
+    p252_ctx::LevelSet*& set = guard.set;
     if (!d_levels && n_leaves > 1) {  // ping-pong in context-owned scratch: the pair of THIS stream (ctx.hpp)
         const size_t l1 = (n_leaves + arity - 1) / arity, l2 = (l1 + arity - 1) / arity;
         int rc = level_set(ctx, st, l1 * 32, l2 * 32, &set);
@@ -381,7 +434,7 @@ int p252host::merkle_tree_device(p252_ctx* ctx, unsigned arity, const uint64_t t
         parity ^= 1;
     }
     HIP_TRY(ctx, hipMemcpyAsync(d_root, cur, 32, hipMemcpyDeviceToDevice, st));
-    return set ? level_set_done(ctx, set) : P252_OK;
+    return guard.finish();
 }
 }  // extern "C++"
 
@@ -411,7 +464,8 @@ static int forest_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], c
         HIP_TRY(ctx, hipMemcpyAsync(d_roots, d_leaves, cur_n * 32, hipMemcpyDeviceToDevice, st));
         return P252_OK;
     }
-    p252_ctx::LevelSet* set = nullptr;
+    LevelSetGuard guard(ctx);
+    p252_ctx::LevelSet*& set = guard.set;
     if (!d_levels) {  // ping-pong in context-owned scratch, this stream's pair (the last level goes straight to d_roots)
         int rc = level_set(ctx, st, cur_n / arity * 32, cur_n / arity / arity * 32 + 32, &set);
         if (rc) return rc;
@@ -434,7 +488,7 @@ static int forest_device(p252_ctx* ctx, unsigned arity, const uint64_t tag[4], c
         cur_n = next_n;
         parity ^= 1;
     }
-    return set ? level_set_done(ctx, set) : P252_OK;
+    return guard.finish();
 }
 
 int p252_merkle4_forest_device(p252_ctx* ctx, const uint64_t tag[4], const void* d_leaves, size_t n_trees, size_t leaves_per_tree,
@@ -587,6 +641,8 @@ static int staged_run(p252_ctx* ctx, size_t n, size_t chunk, const std::vector<H
                 HIP_TRY(ctx, hipMalloc(&S.d_out, out_chunk_b));
                 S.out_cap = out_chunk_b;
             }
+            if (S.in_dirty < in_chunk_b) S.in_dirty = in_chunk_b;
+            if (S.out_dirty < out_chunk_b) S.out_dirty = out_chunk_b;
         }
     }
     std::atomic<size_t> next{0};
@@ -1034,7 +1090,8 @@ static int verify_batch_device(p252_ctx* ctx, unsigned arity, const uint64_t tag
     if (n > (SIZE_MAX / 32)) return fail(ctx, P252_ERR_INVALID_ARGUMENT, who + ": size overflow");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    p252_ctx::LevelSet* set = nullptr;  // the recomputed roots live in the scratch pair of THIS stream (ctx.hpp): n x 32 bytes
+    LevelSetGuard guard(ctx);
+    p252_ctx::LevelSet*& set = guard.set;  // the recomputed roots live in the scratch pair of THIS stream (ctx.hpp): n x 32 bytes
     int rc = level_set(ctx, st, n * 32, 0, &set);
     if (rc) return rc;
     rc = arity == 4 ? p252_merkle4_path_batch_device(ctx, tag, d_leaves, d_siblings, d_positions, depth, set->buf[0], n, hip_stream)
@@ -1043,7 +1100,9 @@ static int verify_batch_device(p252_ctx* ctx, unsigned arity, const uint64_t tag
         const hipError_t e = launch_compare_roots(set->buf[0], d_root, d_ok, n, st);
         if (e != hipSuccess) rc = fail(ctx, P252_ERR_HIP, who + ": " + hipGetErrorString(e));
     }
-    const int rc2 = level_set_done(ctx, set);
+    const std::string msg = ctx->err;
+    const int rc2 = guard.finish();
+    if (rc) ctx->err = msg;
     return rc ? rc : rc2;
 }
 
@@ -1279,10 +1338,16 @@ static int crypt_host(p252_ctx* ctx, int variant, bool decrypt, const uint64_t t
     const int rc = crypt_host_run(ctx, variant, decrypt, tag, in, secrets, nonces, len, out, ok, n, &used_in, &used_out, &used_lanes);
     if (ctx && (used_in || used_out || used_lanes)) {
         const std::string msg = ctx->err;
-        hipError_t e = hipDeviceSynchronize();
+        // nothing of THIS call may still be in flight on what is cleared: the call ran on the staging lanes' streams (non-blocking
+        // streams) or on the null stream — those are synchronised, not the device (other contexts and streams keep running),
+        // and only the bytes the lanes may have written are cleared, not their whole capacity
+        hipError_t e = hipSuccess;
+        for (auto& l : ctx->lanes)
+            if (used_lanes && l.st && e == hipSuccess) e = hipStreamSynchronize(l.st);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e == hipSuccess) e = wipe_span(ctx->d_in, used_in);
         if (e == hipSuccess) e = wipe_span(ctx->d_out, used_out);
-        if (e == hipSuccess && used_lanes) e = wipe_lanes(ctx);
+        if (e == hipSuccess && used_lanes) e = wipe_lanes(ctx, /*dirty_only=*/true);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess && rc == P252_OK) return fail(ctx, P252_ERR_HIP, std::string("encrypt/decrypt: wiping the scratch failed: ") + hipGetErrorString(e));
         ctx->err = msg;

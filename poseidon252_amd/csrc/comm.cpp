@@ -14,8 +14,10 @@
 //
 // xGMI is point-to-point and these messages are 32 bytes x world: the exchange is pure latency (a few microseconds), never
 // bandwidth; there is nothing to bucket or overlap.  It is on the stream so that the HOST never waits for it.
+//
+// RCCL itself is NOT linked: rccl_dyn.hpp resolves the ten entry points used here on the first call that needs them, preferring a
+// copy the process already holds (torch's, the application's).  No RCCL -> P252_ERR_COMM from these entry points only.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +27,8 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "openings.h"
+#include "rccl_dyn.hpp"
 
 using namespace p252host;
 
@@ -48,13 +52,30 @@ struct p252_comm {
     // host thread go inside one ncclGroupStart / ncclGroupEnd
     std::shared_ptr<std::vector<p252_comm*>> clique;
     bool owned_by_ctx = false;  // created lazily by a p252_*_multi_device call: destroyed with its context
+    // a peer's failed local build (k_poison_if_peer_failed, merkle2.hip): 1 + its rank, written by the device into host-mapped memory
+    // behind the top levels of a sharded build; read and cleared by the host at p252_comm_check / p252_sync
+    unsigned* h_fail = nullptr;
+    unsigned* d_fail = nullptr;
 };
+
+// the RCCL entry points (rccl_dyn.hpp): set by the first successful need_rccl() and never changed afterwards — every p252_comm
+// that exists was made through it, so code that holds a communicator may use R without asking again
+static const p252rccl::Api* R = nullptr;
+
+static int need_rccl(p252_ctx* ctx) {
+    if (R) return P252_OK;
+    std::string why;
+    const p252rccl::Api* a = p252rccl::api(&why);
+    if (!a) return fail(ctx, P252_ERR_COMM, why);
+    R = a;
+    return P252_OK;
+}
 
 #define NCCL_TRY(ctx, expr)                                                                         \
     do {                                                                                            \
         ncclResult_t r_ = (expr);                                                                   \
         if (r_ != ncclSuccess)                                                                      \
-            return fail(ctx, P252_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));   \
+            return fail(ctx, P252_ERR_COMM, std::string(#expr) + ": " + R->GetErrorString(r_));    \
     } while (0)
 
 namespace {
@@ -69,6 +90,9 @@ int alloc_buffers(p252_comm* c) {
     HIP_TRY(ctx, hipMalloc(&c->d_top, 32));
     HIP_TRY(ctx, hipMalloc(&c->d_tab_in, host_tables().size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipHostMalloc((void**)&c->h_fail, sizeof(unsigned), hipHostMallocMapped));
+    *c->h_fail = 0;
+    HIP_TRY(ctx, hipHostGetDevicePointer((void**)&c->d_fail, c->h_fail, 0));
     return P252_OK;
 }
 
@@ -88,12 +112,13 @@ int comm_leave(p252_comm* c, hipStream_t st) {
 void free_comm(p252_comm* c, bool abort) {
     if (!c) return;
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
-    if (c->nccl) (void)(abort ? ncclCommAbort(c->nccl) : ncclCommDestroy(c->nccl));
+    if (c->nccl && R) (void)(abort ? R->CommAbort(c->nccl) : R->CommDestroy(c->nccl));
     if (c->d_sub) (void)hipFree(c->d_sub);
     if (c->d_roots) (void)hipFree(c->d_roots);
     if (c->d_top) (void)hipFree(c->d_top);
     if (c->d_tab_in) (void)hipFree(c->d_tab_in);
     if (c->done) (void)hipEventDestroy(c->done);
+    if (c->h_fail) (void)hipHostFree(c->h_fail);
     if (c->ctx && c->ctx->comm == c) c->ctx->comm = nullptr;
     if (c->clique)
         for (auto& p : *c->clique)
@@ -111,15 +136,15 @@ int broadcast_and_validate(const std::vector<p252_comm*>& comms, int root) {
     int rc = P252_OK;
     for (size_t t = 0; t < comms.size(); ++t) scratch[t] = comms[t]->d_tab_in;  // allocated with the communicator, before any collective
     {
-        ncclResult_t r = ncclGroupStart();
+        ncclResult_t r = R->GroupStart();
         for (size_t t = 0; t < comms.size() && r == ncclSuccess; ++t) {
             p252_ctx* ctx = comms[t]->ctx;
             (void)hipSetDevice(ctx->device);
-            r = ncclBroadcast(ctx->d_tab, scratch[t], bytes, ncclUint8, root, comms[t]->nccl, nullptr);
+            r = R->Broadcast(ctx->d_tab, scratch[t], bytes, ncclUint8, root, comms[t]->nccl, nullptr);
         }
-        const ncclResult_t r2 = ncclGroupEnd();
+        const ncclResult_t r2 = R->GroupEnd();
         if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclBroadcast of the constant table: ") + ncclGetErrorString(r));
+        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclBroadcast of the constant table: ") + R->GetErrorString(r));
     }
     std::vector<int32_t> got(ref.size());
     for (size_t t = 0; t < comms.size() && rc == P252_OK; ++t) {
@@ -157,6 +182,17 @@ void release_ctx_comm(p252_ctx* ctx) {
     }
 }
 
+// the host's side of k_poison_if_peer_failed: called where the host has just synchronised with the stream of a sharded build
+// (p252_comm_check, p252_sync).  A set flag is reported once and cleared.
+int comm_take_failure(p252_ctx* ctx) {
+    if (!ctx || !ctx->comm || !ctx->comm->h_fail) return P252_OK;
+    const unsigned f = __atomic_exchange_n(ctx->comm->h_fail, 0u, __ATOMIC_ACQ_REL);
+    if (!f) return P252_OK;
+    return fail(ctx, P252_ERR_COMM,
+                "sharded tree: rank " + std::to_string(f - 1) + " reported a failed local build (its gathered root was the all-ones sentinel); "
+                "the root this rank produced for that build has been overwritten with all-ones and must not be used");
+}
+
 // the communicators of `ctxs` (rank t = ctxs[t]) when they all belong to ONE clique in exactly this order, else empty
 static std::vector<p252_comm*> clique_of(p252_ctx* const* ctxs, size_t n_ctx) {
     std::vector<p252_comm*> v;
@@ -167,6 +203,8 @@ static std::vector<p252_comm*> clique_of(p252_ctx* const* ctxs, size_t n_ctx) {
     v.assign(cl.begin(), cl.end());
     return v;
 }
+
+static std::string g_lazy_refused;  // why the lazy communicator of the *_multi_device entry points could not be made (empty: not tried / made)
 
 static bool distinct_devices(p252_ctx* const* ctxs, size_t n_ctx) {
     // (test-only: tests/test_comm_mock_ranks.py links the library against a mock RCCL that accepts several ranks on one device, to
@@ -183,6 +221,8 @@ static bool distinct_devices(p252_ctx* const* ctxs, size_t n_ctx) {
 }
 
 static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm*>& out, bool owned) {
+    int rc0 = need_rccl(ctxs[0]);
+    if (rc0) return rc0;
     for (size_t t = 0; t < n_ctx; ++t)
         if (ctxs[t]->comm) return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "comm_create_all: context " + std::to_string(t) + " already belongs to a communicator");
     if (!distinct_devices(ctxs, n_ctx))
@@ -207,8 +247,8 @@ static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm
         std::vector<int> devs(n_ctx);
         for (size_t t = 0; t < n_ctx; ++t) devs[t] = ctxs[t]->device;
         std::vector<ncclComm_t> nc(n_ctx, nullptr);
-        const ncclResult_t r = ncclCommInitAll(nc.data(), (int)n_ctx, devs.data());
-        if (r != ncclSuccess) rc = fail(ctxs[0], P252_ERR_COMM, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        const ncclResult_t r = R->CommInitAll(nc.data(), (int)n_ctx, devs.data());
+        if (r != ncclSuccess) rc = fail(ctxs[0], P252_ERR_COMM, std::string("ncclCommInitAll: ") + R->GetErrorString(r));
         for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) out[t]->nccl = nc[t];
     }
     if (rc == P252_OK) rc = broadcast_and_validate(out, 0);
@@ -239,14 +279,14 @@ static int tree_clique(const std::vector<p252_comm*>& comms, const uint64_t tag[
         if (rc == P252_OK) rc = merkle_tree_device(comms[t]->ctx, 4, tag, d_leaves[t], leaves_per_ctx, comms[t]->d_sub, nullptr, hip_streams ? hip_streams[t] : nullptr);
     }
     if (rc == P252_OK) {  // (one host thread drives every rank: a failure above means NO rank has entered the collective yet)
-        ncclResult_t r = ncclGroupStart();
+        ncclResult_t r = R->GroupStart();
         for (size_t t = 0; t < n && r == ncclSuccess; ++t) {
             (void)hipSetDevice(comms[t]->ctx->device);
-            r = ncclAllGather(comms[t]->d_sub, comms[t]->d_roots, 32, ncclUint8, comms[t]->nccl, stream_of(t));
+            r = R->AllGather(comms[t]->d_sub, comms[t]->d_roots, 32, ncclUint8, comms[t]->nccl, stream_of(t));
         }
-        const ncclResult_t r2 = ncclGroupEnd();
+        const ncclResult_t r2 = R->GroupEnd();
         if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclAllGather of the subtree roots: ") + ncclGetErrorString(r));
+        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclAllGather of the subtree roots: ") + R->GetErrorString(r));
     }
     for (size_t t = 0; t < n && rc == P252_OK; ++t) {
         void* dst = (d_root_out && d_root_out[t]) ? d_root_out[t] : comms[t]->d_top;
@@ -261,7 +301,7 @@ static int tree_clique(const std::vector<p252_comm*>& comms, const uint64_t tag[
 // is created on first use and kept), nullptr-result (-> host gather) when they share a device — RCCL refuses two ranks on
 // one GPU, and that is the single-GPU test configuration — or when P252_MULTI_HOST_GATHER=1 asks for it.
 int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves, size_t leaves_per_ctx,
-                           void* const* d_root_out, void* const* hip_streams, bool* used_rccl) {
+                           void* const* d_root_out, void* const* hip_streams, bool* used_rccl, std::string* unavailable_why) {
     *used_rccl = false;
     static const bool host_gather = [] {
         const char* e = std::getenv("P252_MULTI_HOST_GATHER");
@@ -282,6 +322,12 @@ int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t t
         if (host_gather || !distinct_devices(ctxs, n_ctx)) return P252_OK;
         static std::mutex mu;  // one lazy creation at a time
         std::lock_guard<std::mutex> lk(mu);
+        // a lazy creation that failed once is not retried on every call (ncclCommInitAll takes 0.1-1 s to refuse): the reason
+        // is kept for p252_merkle4_tree_multi_device_resident's message, the caller of this function gathers through the host
+        if (!g_lazy_refused.empty()) {
+            if (unavailable_why) *unavailable_why = g_lazy_refused;
+            return P252_OK;
+        }
         // ABI 5 accepted ANY array of contexts.  A context that already sits in a communicator over ANOTHER array (other count,
         // order or subset — ctxs[:4] after ctxs[:8]) must not make the call fail:
         //  * a communicator the CALLER made (p252_comm_create_rank / _create_all) is the caller's to keep: the roots are gathered
@@ -302,7 +348,9 @@ int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t t
                 for (p252_comm* m : members) free_comm(m, false);
             }
         int rc = create_all(ctxs, n_ctx, comms, /*owned=*/true);
-        if (rc) {  // no communicator to be had (ncclCommInitAll refused): the host gather still exists — the caller takes it
+        if (rc) {  // no communicator to be had (no RCCL in the process, ncclCommInitAll refused): the host gather still exists — the caller takes it
+            g_lazy_refused = ctxs[0]->err.empty() ? std::string("communicator creation failed") : ctxs[0]->err;
+            if (unavailable_why) *unavailable_why = g_lazy_refused;
             ctxs[0]->err.clear();
             return P252_OK;
         }
@@ -317,8 +365,10 @@ extern "C" {
 
 int p252_comm_unique_id(void* id_out, size_t len) {
     if (!id_out || len != P252_COMM_ID_BYTES) return fail(nullptr, P252_ERR_INVALID_ARGUMENT, "comm_unique_id: id_out must hold P252_COMM_ID_BYTES bytes");
+    int rc = need_rccl(nullptr);
+    if (rc) return rc;
     ncclUniqueId id;
-    NCCL_TRY(nullptr, ncclGetUniqueId(&id));
+    NCCL_TRY(nullptr, R->GetUniqueId(&id));
     std::memcpy(id_out, id.internal, P252_COMM_ID_BYTES);
     return P252_OK;
 }
@@ -329,6 +379,8 @@ int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, i
     if (!id || len != P252_COMM_ID_BYTES) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: id must be the P252_COMM_ID_BYTES bytes of p252_comm_unique_id");
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: need 0 <= rank < world");
     if (ctx->comm) return fail(ctx, P252_ERR_INVALID_ARGUMENT, "comm_create_rank: the context already belongs to a communicator");
+    int rc = need_rccl(ctx);
+    if (rc) return rc;
     // every allocation BEFORE the first collective: a rank that cannot allocate returns here, while its peers have not yet entered
     // anything they would wait in for it; from ncclCommInitRank on, creation is collective — a failure on one rank (reported on
     // that rank) aborts its communicator, and the job must treat it as the failure of all (header: "collective")
@@ -336,12 +388,12 @@ int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, i
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
-    int rc = alloc_buffers(c);
+    rc = alloc_buffers(c);
     if (rc == P252_OK) {
         ncclUniqueId uid;
         std::memcpy(uid.internal, id, P252_COMM_ID_BYTES);
-        const ncclResult_t r = ncclCommInitRank(&c->nccl, world, uid, rank);
-        if (r != ncclSuccess) rc = fail(ctx, P252_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+        const ncclResult_t r = R->CommInitRank(&c->nccl, world, uid, rank);
+        if (r != ncclSuccess) rc = fail(ctx, P252_ERR_COMM, std::string("ncclCommInitRank: ") + R->GetErrorString(r));
     }
     if (rc == P252_OK) {
         ctx->comm = c;
@@ -369,6 +421,24 @@ int p252_comm_create_all(p252_ctx* const* ctxs, size_t n_ctx, p252_comm** comms_
 
 void p252_comm_destroy(p252_comm* comm) { free_comm(comm, false); }
 
+int p252_comm_check(p252_comm* comm, void* hip_stream) {
+    if (!comm || !comm->ctx) return P252_ERR_INVALID_ARGUMENT;
+    p252_ctx* ctx = comm->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+    return comm_take_failure(ctx);
+}
+
+int p252_comm_backend(char* path_out, size_t len) {
+    const int rc = need_rccl(nullptr);
+    if (rc) return rc;
+    if (path_out && len) {
+        std::strncpy(path_out, R->origin.c_str(), len - 1);
+        path_out[len - 1] = 0;
+    }
+    return P252_OK;
+}
+
 int p252_comm_rank(const p252_comm* comm) { return comm ? comm->rank : -1; }
 int p252_comm_size(const p252_comm* comm) { return comm ? comm->world : 0; }
 
@@ -387,18 +457,21 @@ int p252_merkle4_tree_sharded_device(p252_comm* comm, const uint64_t tag[4], con
     if (rc) {
         // A LOCAL failure (allocation of the level scratch) must not leave the peers blocked on the stream in a collective this
         // rank never enters: the rank still contributes — an all-ones root, which is no BlsScalar (>= p) — and returns
-        // its error; the job treats one rank's failure as the build's, as with any collective.
+        // its error.  Its peers find the sentinel on the device (k_poison_if_peer_failed below): their root becomes all-ones too and
+        // p252_comm_check / p252_sync report P252_ERR_COMM naming this rank (they used to return a garbage root as P252_OK).
         const std::string msg = ctx->err;
         (void)hipMemsetAsync(comm->d_sub, 0xff, 32, st);
-        (void)ncclAllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st);
+        (void)R->AllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st);
         (void)comm_leave(comm, st);
         ctx->err = msg;
         return rc;
     }
     // ... the path's only exchange step, on the same stream: world x 32 bytes to every rank ...
-    NCCL_TRY(ctx, ncclAllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st));
+    NCCL_TRY(ctx, R->AllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st));
     // ... and the top levels, on every rank (a single rank's "tree over one root" is a copy)
     rc = merkle_tree_device(ctx, 4, tag, comm->d_roots, (size_t)comm->world, d_root, nullptr, hip_stream);
+    if (rc == P252_OK && p252::launch_poison_if_peer_failed(comm->d_roots, (unsigned)comm->world, d_root, comm->d_fail, st) != hipSuccess)
+        rc = fail(ctx, P252_ERR_HIP, "merkle_tree_sharded: launching the failed-peer check failed");
     const int rc2 = comm_leave(comm, st);
     return rc ? rc : rc2;
 }
@@ -411,12 +484,17 @@ int p252_merkle4_tree_multi_device_resident(p252_ctx* const* ctxs, size_t n_ctx,
     if (!power_of_4(leaves_per_ctx))
         return fail(ctxs[0], P252_ERR_INVALID_ARGUMENT, "merkle_tree_multi_device_resident: every device must own a complete subtree (4^k leaves)");
     bool used = false;
-    rc = tree_multi_device_rccl(ctxs, n_ctx, tag, d_leaves, leaves_per_ctx, d_root_out, hip_streams, &used);
+    std::string why;
+    rc = tree_multi_device_rccl(ctxs, n_ctx, tag, d_leaves, leaves_per_ctx, d_root_out, hip_streams, &used, &why);
     if (rc) return rc;
+    if (!used && !why.empty())  // RCCL itself said no (or is not in the process): its own words, not a guess
+        return fail(ctxs[0], P252_ERR_COMM, "merkle_tree_multi_device_resident: no RCCL communicator over the contexts: " + why +
+                                                 " (p252_merkle4_tree_multi_device gathers through the host in that case)");
     if (!used)
         return fail(ctxs[0], P252_ERR_COMM,
-                    "merkle_tree_multi_device_resident needs an RCCL communicator over the contexts: they share a device (RCCL wants one per rank) "
-                    "or P252_MULTI_HOST_GATHER=1 is set; p252_merkle4_tree_multi_device gathers through the host in that case");
+                    "merkle_tree_multi_device_resident needs an RCCL communicator over the contexts: they share a device (RCCL wants one per rank), "
+                    "one of them belongs to a communicator the caller made over another array, or P252_MULTI_HOST_GATHER=1 is set; "
+                    "p252_merkle4_tree_multi_device gathers through the host in that case");
     return P252_OK;
 }
 

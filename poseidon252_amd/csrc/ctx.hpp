@@ -43,6 +43,7 @@ struct p252_ctx {
         void* d_in = nullptr;
         void* d_out = nullptr;
         size_t in_cap = 0, out_cap = 0;
+        size_t in_dirty = 0, out_dirty = 0;  // bytes calls may have written since the last wipe (<= cap): what a per-call wipe clears
         hipEvent_t done = nullptr;
     };
     struct Lane {  // one worker thread + stream, double-buffered: the host copy of chunk c+1 overlaps the DMA / kernel of chunk c
@@ -79,7 +80,9 @@ void release_ctx_comm(p252_ctx* ctx);  // p252_destroy: a communicator the libra
 // the sharded tree over an array of contexts through RCCL (communicator created on first use); *used_rccl = false and
 // P252_OK when the contexts cannot form one (shared device) or P252_MULTI_HOST_GATHER=1: the caller gathers through the host
 int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t tag[4], const void* const* d_leaves, size_t leaves_per_ctx,
-                           void* const* d_root_out, void* const* hip_streams, bool* used_rccl);
+                           void* const* d_root_out, void* const* hip_streams, bool* used_rccl, std::string* unavailable_why = nullptr);
+// a peer's failed local build seen by this context's communicator since the last call (comm.cpp): P252_ERR_COMM once, then cleared
+int comm_take_failure(p252_ctx* ctx);
 }  // namespace p252host
 
 #define HIP_TRY(ctx, expr)                                                                  \

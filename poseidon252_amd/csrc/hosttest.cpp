@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "coop29.hpp"
+#include "fastdiv.hpp"
 #include "hades29.hpp"
 #include "_gen/assets.inc"
 
@@ -28,6 +29,25 @@ static const std::vector<int32_t>& tab29() {
 }
 
 extern "C" {
+// openings.hip's FAST extraction kernel: record index / depth through fastdiv.hpp.  Returns the number of mismatches with the
+// true quotient over recs[0..n) (and the first one in *first_bad); round 5's 40-bit multiply-shift is mode 1, kept to show the test
+// sees what ADVICE r5 found.
+size_t ht_fastdiv_check(const uint32_t* recs, size_t n, unsigned depth, int mode, uint32_t* first_bad) {
+    const unsigned long long m = fast_div_reciprocal(depth), m40 = ((1ull << 40) / depth) + 1;
+    size_t bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned q = mode == 1 ? (unsigned)(((unsigned long long)recs[i] * m40) >> 40) : fast_div(recs[i], m);
+        if (q != recs[i] / depth && !bad++ && first_bad) *first_bad = recs[i];
+    }
+    return bad;
+}
+// every rec in [lo, hi) — a dense sweep without marshalling 2^32 indices
+size_t ht_fastdiv_sweep(uint64_t lo, uint64_t hi, unsigned depth) {
+    const unsigned long long m = fast_div_reciprocal(depth);
+    size_t bad = 0;
+    for (uint64_t r = lo; r < hi; ++r) bad += fast_div((unsigned)r, m) != (unsigned)r / depth;
+    return bad;
+}
 int ht_tables29_total() { return Tab29Layout::TOTAL; }
 void ht_tables29(int32_t* out) { std::memcpy(out, tab29().data(), sizeof(int32_t) * Tab29Layout::TOTAL); }
 

@@ -85,4 +85,33 @@ hipError_t launch_compare_roots(const void* roots, const void* expected, void* o
     return hipGetLastError();
 }
 
+// ---- a failed peer in a sharded build (comm.cpp): a rank whose local subtree build fails still enters the all-gather, with
+// an all-ones "root" (no BlsScalar: >= p), so that its peers are not left blocked.  This kernel, behind the top levels on every healthy
+// rank, looks for that sentinel among the gathered roots: found -> the final root is overwritten with all-ones as well (nothing
+// downstream can take it for a digest) and 1 + the failing rank goes to *fail_flag, a word of host-mapped memory the host reads at its
+// next synchronisation point (p252_comm_check, p252_sync).  One wave; world x 32 bytes read. ----
+__global__ void __launch_bounds__(64) k_poison_if_peer_failed(const uint4* __restrict__ roots, unsigned world, uint4* __restrict__ root_out,
+                                                              unsigned* __restrict__ fail_flag) {
+    unsigned first = 0xffffffffu;
+    for (unsigned r = threadIdx.x; r < world; r += 64) {
+        const uint4 a = roots[2 * r], b = roots[2 * r + 1];
+        if ((a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w) == 0xffffffffu && r < first) first = r;
+    }
+    for (int off = 32; off; off >>= 1) {
+        const unsigned o = __shfl_xor(first, off);
+        first = o < first ? o : first;
+    }
+    if (threadIdx.x == 0 && first != 0xffffffffu) {
+        const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        root_out[0] = ones;
+        root_out[1] = ones;
+        __hip_atomic_store(fail_flag, first + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_poison_if_peer_failed(const void* roots, unsigned world, void* root_out, unsigned* fail_flag, hipStream_t st) {
+    hipLaunchKernelGGL(k_poison_if_peer_failed, dim3(1), dim3(64), 0, st, static_cast<const uint4*>(roots), world, static_cast<uint4*>(root_out), fail_flag);
+    return hipGetLastError();
+}
+
 }  // namespace p252

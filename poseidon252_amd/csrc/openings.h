@@ -27,4 +27,8 @@ hipError_t launch_merkle2_path(const int32_t* tab, const TagArg& tag, const void
 // merkle2.hip: ok[i] = (roots[i] == *expected), one byte per opening (Opening::verify in bulk, behind either arity's re-hash)
 hipError_t launch_compare_roots(const void* roots, const void* expected, void* ok, size_t n, hipStream_t st);
 
+// merkle2.hip: sharded builds (comm.cpp) — a gathered root of all-ones is a failed peer's sentinel: poison root_out (32 B, all-ones) and
+// store 1 + that rank in *fail_flag (device pointer of a host-mapped word)
+hipError_t launch_poison_if_peer_failed(const void* roots, unsigned world, void* root_out, unsigned* fail_flag, hipStream_t st);
+
 }  // namespace p252

@@ -14,6 +14,7 @@
 
 #include <cstdlib>
 
+#include "fastdiv.hpp"
 #include "openings.h"
 
 namespace p252 {
@@ -38,9 +39,10 @@ __device__ __forceinline__ uint4 load_or_zero(const uint4* __restrict__ base, si
 // FAST (round 5; 32-bit lane indices only): what the counters of round 4's kernel pointed at was not memory (0.41-0.43 of HBM peak by
 // FETCH_SIZE / WRITE_SIZE) but per-lane integer work around ONE 16-byte load and ONE 16-byte store — a 32-bit division by `depth`
 // (~30 instructions with a quarter-rate reciprocal) and a DIVERGENT loop of up to `depth` trips for the level's offset (lanes of a
-// wave sit on ~11 different levels).  FAST: the division is a multiply-shift with a host-computed reciprocal (exact for every
-// record index a 32-bit launch can hold), and the `depth` (offset, count) pairs are computed ONCE per block by its first `depth`
-// lanes into LDS (512 B) and read back with one ds_read per lane.
+// wave sit on ~11 different levels).  FAST: the division is the high half of a product with a host-computed 64-bit reciprocal
+// (fastdiv.hpp: exact for every record index < 2^32 and depth <= 64; round 5's 40-bit multiply-shift wrapped from opening
+// 2^24 on — ADVICE r5), and the `depth` (offset, count) pairs are computed ONCE per block by its first `depth` lanes into LDS
+// (512 B) and read back with one ds_read per lane.
 struct LevelRef {
     unsigned long long first;  // index of the level's first 16-byte word, relative to `levels` (level 0: the leaves, unused)
     unsigned long long cnt;    // nodes in the level
@@ -77,8 +79,7 @@ __global__ void __launch_bounds__(256) k_merkle4_openings(const uint4* __restric
     if (t >= (IDX)(k * depth * PIECES)) return;
     const IDX rec = t / PIECES;
     const unsigned piece = (unsigned)(t - rec * PIECES), sib = piece >> 1, half = piece & 1u;
-    // FAST: rec < 2^32 / PIECES and depth <= 64: floor(rec * ceil(2^40 / depth) / 2^40) == rec / depth exactly
-    const IDX i = FAST ? (IDX)(((unsigned long long)rec * inv_depth) >> 40) : rec / (IDX)depth;
+    const IDX i = FAST ? (IDX)fast_div((unsigned)rec, inv_depth) : rec / (IDX)depth;
     const unsigned l = (unsigned)(rec - i * depth);
     const size_t leaf = index[i];
     const bool bad = leaf >= n_leaves;
@@ -119,7 +120,7 @@ static hipError_t launch_openings(const void* leaves, size_t n_leaves, const voi
         const char* e = std::getenv("P252_OPENINGS_FAST");
         return !(e && e[0] == '0');
     }();
-    const unsigned long long inv_depth = depth ? ((1ull << 40) / depth) + 1 : 0;
+    const unsigned long long inv_depth = fast_div_reciprocal(depth);
     if (lanes + 256 <= 0xffffffffull && fast && depth >= 1 && depth <= 64)
         hipLaunchKernelGGL((k_merkle4_openings<uint32_t, ARITY, true>), grid, dim3(256), 0, st, static_cast<const uint4*>(leaves), n_leaves,
                            static_cast<const uint4*>(levels), static_cast<const uint32_t*>(index), k, depth, static_cast<uint4*>(leaves_out),

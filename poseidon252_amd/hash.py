@@ -40,8 +40,9 @@ class DeviceError(RuntimeError):
     """HIP failure or no device: there is no CPU fallback."""
 
 
-def _raise(rc, ctx_handle=None):
-    msg = _lib.lib().p252_last_error(ctx_handle).decode() if ctx_handle is not None else ""
+def _raise(rc, ctx_handle=None, global_err=False):
+    """global_err: the failing call had no context (p252_comm_unique_id, p252_comm_backend) — its message is p252_last_error(NULL)"""
+    msg = _lib.lib().p252_last_error(ctx_handle).decode() if (ctx_handle is not None or global_err) else ""
     if rc == _lib.ERR_IO_PATTERN_VIOLATION:
         raise IOPatternViolation("io-pattern should be valid: IOPatternViolation " + msg)
     if rc == _lib.ERR_INVALID_IO_PATTERN:
@@ -151,10 +152,23 @@ class Context:
         self._check(_lib.lib().p252_permute_batch(self._h, s.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p), s.shape[0]))
         return out
 
+    def sync(self, stream=None):
+        """wait for `stream` (a torch stream; default: the current one) — p252_sync; raises DeviceError if a sharded tree build of this
+        context's communicator met a failed peer since the last check (comm.Comm.check)"""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream()
+        self._check(_lib.lib().p252_sync(self._h, ctypes.c_void_p(stream.cuda_stream)))
+
     def wipe(self):
         """clear every scratch buffer the context owns (p252_wipe: device scratch, level scratch, staging lanes).  The host-buffer
         encrypt / decrypt calls and close() do this themselves (the reference builds with `zeroize`, Cargo.toml:14)."""
         self._check(_lib.lib().p252_wipe(self._h))
+
+    def trim(self):
+        """give the grow-only scratch back (p252_trim: waits for the device, wipes, frees; the next call allocates again) — the
+        reference holds no state at all (hash.rs:92-96)"""
+        self._check(_lib.lib().p252_trim(self._h))
 
     def scratch_residue(self):
         """diagnostics: non-zero bytes in the context's scratch buffers (p252_scratch_residue)"""

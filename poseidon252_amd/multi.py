@@ -61,6 +61,7 @@ def merkle4_tree_multi_device(ctxs, tag, d_leaves, leaves_per_ctx):
     k = len(ctxs)
     ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in d_leaves])
     root = np.empty(4, dtype=np.uint64)
+    _lib.prefer_torch_rccl()  # (contexts on distinct devices exchange their roots over RCCL: one copy per process)
     _check(ctxs, _lib.lib().p252_merkle4_tree_multi_device(_ctx_array(ctxs), k, tag.ctypes.data_as(_u64p), ptrs, leaves_per_ctx,
                                                             root.ctypes.data_as(_u64p)))
     return root

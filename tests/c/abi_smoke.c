@@ -107,6 +107,14 @@ int main(void) {
         CHECK(p252_merkle4_tree_sharded_device(comm, tag, d_leaves, 4 * (size_t)N, d_root, NULL) == P252_OK);
         CHECK(hipDeviceSynchronize() == 0 && hipMemcpy(root3, d_root, 32, 2) == 0 && memcmp(root3, root, 32) == 0);
         CHECK(p252_merkle4_tree_sharded_device(comm, tag, d_leaves, 3, d_root, NULL) == P252_ERR_INVALID_ARGUMENT); /* not 4^k */
+        /* ABI 8: no peer failed (p252_comm_check waits for the stream itself; p252_sync reports the same); RCCL was resolved at run
+         * time — a C program has one copy, the one the loader finds — and p252_comm_backend says which */
+        CHECK(p252_comm_check(comm, NULL) == P252_OK && p252_sync(ctx, NULL) == P252_OK && p252_comm_check(NULL, NULL) == P252_ERR_INVALID_ARGUMENT);
+        {
+            char where[1024];
+            where[0] = 0;
+            CHECK(p252_comm_backend(where, sizeof where) == P252_OK && strstr(where, "rccl") != NULL && p252_comm_backend(NULL, 0) == P252_OK);
+        }
         p252_comm_destroy(comm);
         /* one process per GPU: rank 0 makes the id, every rank joins with it (here: world = 1) */
         {
@@ -179,6 +187,10 @@ int main(void) {
         CHECK(p252_wipe(ctx) == P252_OK && p252_scratch_residue(ctx, &residue) == P252_OK && residue == 0);
         CHECK(p252_hash_batch(ctx, tag, in, 4, 1, out2, N) == P252_OK && memcmp(out, out2, 32 * (size_t)N) == 0); /* works as before */
         CHECK(p252_wipe(NULL) == P252_ERR_INVALID_ARGUMENT && p252_scratch_residue(ctx, NULL) == P252_ERR_INVALID_ARGUMENT);
+        /* ABI 8: p252_trim frees the grow-only scratch (the next call allocates again) */
+        CHECK(p252_trim(ctx) == P252_OK && p252_scratch_residue(ctx, &residue) == P252_OK && residue == 0 && p252_trim(NULL) == P252_ERR_INVALID_ARGUMENT);
+        CHECK(p252_hash_batch(ctx, tag, in, 4, 1, out2, N) == P252_OK && memcmp(out, out2, 32 * (size_t)N) == 0);
+        CHECK(p252_merkle4_tree(ctx, tag, in, 4 * (size_t)N, root2, NULL) == P252_OK && memcmp(root2, root, 32) == 0 && p252_trim(ctx) == P252_OK);
     }
     /* error paths return codes, nothing unwinds */
     CHECK(p252_hash_batch(ctx, tag, in, 0, 1, out, N) == P252_ERR_INVALID_IO_PATTERN && strlen(p252_last_error(ctx)) > 0);

@@ -1,5 +1,6 @@
-"""Driver of tests/test_comm_mock_ranks.py — runs in a subprocess whose P252_LIB_PATH names the library linked against
-tests/cpp/mock_rccl.cpp (several ranks on ONE device).  Prints one JSON line with what it verified."""
+"""Driver of tests/test_comm_mock_ranks.py — runs in a subprocess whose P252_RCCL_PATH names tests/cpp/mock_rccl.cpp built as a
+shared object: the SHIPPED library resolves it as its RCCL (csrc/rccl_dyn.hpp), several ranks on ONE device.  Prints one JSON line
+with what it verified."""
 import json
 import os
 import sys
@@ -14,7 +15,8 @@ import oracle
 import poseidon252_amd as P
 from poseidon252_amd import comm as C, multi
 
-assert os.environ.get("P252_LIB_PATH") and os.environ.get("P252_COMM_ALLOW_SHARED_DEVICE") == "1"
+assert os.environ.get("P252_RCCL_PATH") and not os.environ.get("P252_LIB_PATH") and os.environ.get("P252_COMM_ALLOW_SHARED_DEVICE") == "1"
+assert os.path.samefile(C.backend(), os.environ["P252_RCCL_PATH"]), C.backend()  # the resolver took the mock, nothing else
 tag = P.merkle4_tag()
 report = {}
 
@@ -73,6 +75,79 @@ def ranks_in_threads(world, per, seed, repeats):
 for world, per in ((8, 4 ** 5), (2, 4 ** 6), (3, 4 ** 3), (5, 16), (8, 1)):
     ranks_in_threads(world, per, 0xC10D + world, repeats=3)
 report["one thread per rank (p252_comm_create_rank + p252_merkle4_tree_sharded_device)"] = "worlds 8, 2, 3, 5, 8 x 3 builds: every rank's root == the oracle's tree over the concatenation"
+
+
+
+def a_rank_fails(world, per, bad_rank, seed):
+    """one rank's LOCAL build fails (here: a misaligned leaf pointer, refused by the tree builder after the communicator
+    bookkeeping) — it returns its error and still enters the all-gather with the all-ones sentinel.  Every healthy rank: the call
+    itself has returned P252_OK (asynchronous), the root on the device is all-ones, p252_comm_check reports P252_ERR_COMM naming the
+    failed rank — once; a following healthy build on the same communicator gives the oracle's root again."""
+    lv = leaves_of(world, per, seed)
+    exp = oracle.merkle4_tree(tag, np.concatenate(lv))[0]
+    box, errs, seen = {}, [], [None] * world
+    ready = threading.Barrier(world)
+
+    def exchange_for(rank):
+        def exchange(id_bytes):
+            if rank == 0:
+                box["id"] = id_bytes
+            ready.wait()
+            return box["id"]
+        return exchange
+
+    def run(rank):
+        try:
+            ctx = P.Context(0)
+            c = C.Comm.create_rank(ctx, rank, world, exchange_for(rank))
+            raw = torch.zeros(per * 4 + 1, dtype=torch.int64, device="cuda:0")
+            raw[:per * 4] = torch.from_numpy(lv[rank].view(np.int64).copy()).reshape(-1).to("cuda:0")
+            good = raw[:per * 4]
+            d_root = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+            if rank == bad_rank:
+                shifted = raw[1:per * 4 + 1]  # 8 bytes off a 16-byte boundary
+                try:
+                    c.merkle4_tree_sharded_device(tag, shifted, per, d_root)
+                    raise AssertionError("the misaligned build was accepted")
+                except ValueError:
+                    seen[rank] = "error returned"
+            else:
+                c.merkle4_tree_sharded_device(tag, good, per, d_root)  # P252_OK: the failure is a peer's and the call is asynchronous
+                torch.cuda.synchronize()
+                assert (d_root.cpu().numpy().view(np.uint64) == np.uint64(0xffffffffffffffff)).all(), "rank %d: root not poisoned" % rank
+                try:
+                    c.check()
+                    raise AssertionError("p252_comm_check did not report the failed peer")
+                except P.DeviceError as e:
+                    assert "rank %d " % bad_rank in str(e), str(e)
+                c.check()  # reported once
+                seen[rank] = "poisoned + reported"
+            ready.wait()
+            d_root.zero_()
+            c.merkle4_tree_sharded_device(tag, good, per, d_root)  # the communicator is still usable
+            c.check()
+            assert np.array_equal(d_root.cpu().numpy().view(np.uint64), exp), "rank %d: root after the failure differs" % rank
+            ready.wait()
+            c.destroy()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append("rank %d: %r" % (rank, e))
+            try:
+                ready.abort()
+            except Exception:
+                pass
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs and not any(t.is_alive() for t in ts), errs
+    assert seen[bad_rank] == "error returned" and all(s == "poisoned + reported" for r, s in enumerate(seen) if r != bad_rank), seen
+
+
+for world, per, bad in ((4, 4 ** 3, 2), (8, 16, 0), (3, 4, 2)):
+    a_rank_fails(world, per, bad, 0xBAD0 + world)
+report["a rank's local build fails (sentinel in the all-gather)"] = "worlds 4, 8, 3: healthy ranks' root poisoned, p252_comm_check names the rank once, next build correct"
 
 # one process, an array of contexts (p252_comm_create_all; one thread drives every rank inside ncclGroupStart / End)
 for world, per in ((8, 4 ** 5), (4, 4 ** 4), (3, 4 ** 2), (6, 4)):

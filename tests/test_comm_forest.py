@@ -1,7 +1,7 @@
 """RCCL inside the library (p252_comm_*, p252_merkle4_tree_sharded_device, the RCCL path of p252_merkle4_tree_multi_device)
 and the forest entry point (p252_merkle4_forest_device).
 
-CPU part: the library links librccl and exports the communicator entry points.  GPU part (one GPU here: world = 1 on the
+CPU part: the library exports the communicator entry points and does NOT link librccl (resolved at run time since ABI 8).  GPU part (one GPU here: world = 1 on the
 real backend — RCCL refuses two ranks on one device, so the >1-rank composition is covered by the gloo / shared-GPU bench
 tests and by the driver's 8-GPU run): both ways to create a communicator, the sharded tree against the oracle, the
 multi-device entry point creating its communicator itself, and forests of every shape against per-tree oracle roots."""
@@ -15,13 +15,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_links_rccl_and_exports_the_communicator():
+def test_library_exports_the_communicator_without_linking_rccl():
     from poseidon252_amd import _lib
     dyn = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH]).decode()
-    assert "librccl.so" in dyn and "libamdhip64.so" in dyn, dyn
+    assert "librccl" not in dyn and "libamdhip64.so" in dyn, dyn  # RCCL is no load-time dependency
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH]).decode()
+    assert " nccl" not in undefined, undefined
     L = ctypes.CDLL(_lib.LIB_PATH)
     for s in ("p252_comm_unique_id", "p252_comm_create_rank", "p252_comm_create_all", "p252_comm_destroy", "p252_comm_rank",
-              "p252_comm_size", "p252_merkle4_tree_sharded_device", "p252_merkle4_tree_multi_device_resident", "p252_merkle4_forest_device"):
+              "p252_comm_size", "p252_comm_check", "p252_comm_backend", "p252_merkle4_tree_sharded_device",
+              "p252_merkle4_tree_multi_device_resident", "p252_merkle4_forest_device"):
         assert hasattr(L, s), s
     # argument checks that need no device
     L.p252_comm_rank.argtypes = L.p252_comm_size.argtypes = [ctypes.c_void_p]
@@ -186,16 +189,20 @@ def test_forest_argument_errors(gpu_ctx):
 
 def test_library_before_torch_exits_cleanly():
     """Found on the GPU box in round 4: with torch's bundled librccl pre-loaded RTLD_GLOBAL ahead of `import torch` the
-    process aborted at exit ("double free or corruption").  _lib.py loads it locally now (one RCCL per process all the
-    same: the loader satisfies the library's NEEDED librccl.so.1 from any loaded object of that SONAME).  Reproducible
-    without a GPU: load the library first, import torch, exit."""
+    process aborted at exit ("double free or corruption").  Since ABI 8 the library does not link RCCL at all; its Python
+    wrappers map torch's copy LOCALLY before the first communicator call when torch is installed but not yet imported
+    (_lib.prefer_torch_rccl), and the library's resolver then takes the copy the process holds: ONE RCCL per process in either
+    import order.  Reproducible without a GPU: load the library first, resolve RCCL, import torch, exit."""
     import sys
-    code = ("from poseidon252_amd import _lib\n_lib.lib()\nimport torch\n"
-            "print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l)))\n")
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, timeout=300)
-    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()[-2000:]
-    libs = eval(r.stdout.decode().strip().splitlines()[-1])
-    assert len(libs) == 1, libs  # torch's copy serves both
+    for code in ("from poseidon252_amd import _lib, comm\n_lib.lib()\nb = comm.backend()\nimport torch\n",
+                 "import torch\nfrom poseidon252_amd import _lib, comm\n_lib.lib()\nb = comm.backend()\n",
+                 "from poseidon252_amd import _lib, comm\n_lib.lib()\nimport torch\nb = comm.backend()\n"):
+        code += "import os\nlibs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l))\nprint([libs, os.path.realpath(b)])\n"
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()[-2000:]
+        libs, backend = eval(r.stdout.decode().strip().splitlines()[-1])
+        assert len(libs) == 1 and os.path.realpath(libs[0]) == backend, (libs, backend)  # torch's copy serves both
+        assert os.sep + "torch" + os.sep in backend, backend
 
 
 @pytest.mark.gpu

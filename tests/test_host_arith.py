@@ -363,3 +363,34 @@ def test_cooperative_digest_lane_groups(oracle_mod, hosttest_lib, lanes):
         assert 2 ** 58 < col < 2 ** 62.6, math.log2(col)
         assert top < 2 ** 27, math.log2(top)
         print("cooperative schedule, %d lanes: max |column| 2^%.2f, max |top digit| 2^%.2f" % (lanes, math.log2(col), math.log2(top)))
+
+
+def test_openings_fast_division_is_exact_over_the_32_bit_range(hosttest_lib):
+    """openings.hip's FAST extraction kernel turns the lane's record index into (opening, level) with fastdiv.hpp's reciprocal
+    product.  ADVICE r5: round 5's 40-bit multiply-shift wrapped from opening 2^24 on (record >= 2^24 * depth) and nothing
+    tested it.  Boundary records of every depth 1..64, a dense sweep around the old failure point, and the old formula as the
+    control that this test would have caught it."""
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    L = hosttest_lib
+    L.ht_fastdiv_check.restype = ctypes.c_size_t
+    L.ht_fastdiv_check.argtypes = [u32p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, u32p]
+    L.ht_fastdiv_sweep.restype = ctypes.c_size_t
+    L.ht_fastdiv_sweep.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint]
+    rng = np.random.default_rng(5)
+    for depth in range(1, 65):
+        q = np.concatenate([np.arange(0, 4), (1 << np.arange(1, 32)), rng.integers(0, (1 << 32) // depth, 4096)]).astype(np.uint64)
+        recs = np.concatenate([q * depth + d for d in (0, 1, depth - 1)] + [q * depth - 1])
+        recs = np.concatenate([recs[(recs >= 0) & (recs < (1 << 32))], [(1 << 32) - 1, (1 << 32) - 2, (1 << 32) - depth]])
+        recs = np.ascontiguousarray(recs.astype(np.uint32))
+        first = ctypes.c_uint32(0)
+        bad = L.ht_fastdiv_check(recs.ctypes.data_as(u32p), recs.size, depth, 0, ctypes.byref(first))
+        assert bad == 0, "depth %d: %d wrong quotients, first at record %d" % (depth, bad, first.value)
+    # the records round 5's kernel got wrong: opening 2^24 at depths 10 / 12 / 20 (the ADVICE's numbers), swept densely
+    for depth in (10, 12, 20):
+        lo = (1 << 24) * depth - 1000
+        assert L.ht_fastdiv_sweep(lo, lo + 2_000_000, depth) == 0
+        recs = np.arange(lo, lo + 4096, dtype=np.uint32)
+        assert L.ht_fastdiv_check(recs.ctypes.data_as(u32p), recs.size, depth, 1, None) > 0  # the old multiply-shift fails here
+    # the top of the 32-bit range, densely, for the depths of the configs (2^24 leaves: 12; 2^20: 10) and the extremes
+    for depth in (1, 2, 3, 7, 10, 12, 13, 32, 63, 64):
+        assert L.ht_fastdiv_sweep((1 << 32) - 3_000_000, 1 << 32, depth) == 0

@@ -20,7 +20,7 @@ KERNEL_SOURCES = ("kernels.hip", "fr29.hpp", "hades29.hpp", "coop29.hpp", "table
 
 def kernel_sources_sha256(kernel=None):
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES + (("openings.hip",) if kernel and "openings" in kernel else ()):  # = bench.py's rule
+    for f in KERNEL_SOURCES + (("openings.hip", "fastdiv.hpp") if kernel and "openings" in kernel else ()):  # = bench.py's rule
         h.update(open(os.path.join(ROOT, "poseidon252_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
