@@ -37,7 +37,7 @@ python3 - "$RC" <<'PY'
 import json, re, sys
 rc = int(sys.argv[1])
 log = open("RUSTPARITY.log").read()
-out = {"ok": rc == 0, "cargo_exit_code": rc, "tests": {}, "tag_inputs": {}, "encryption": {}, "log": "RUSTPARITY.log"}
+out = {"ok": rc == 0, "cargo_exit_code": rc, "tests": {}, "tag_inputs": {}, "encryption": {}, "truncated": {}, "trees": {}, "log": "RUSTPARITY.log"}
 for m in re.finditer(r"^test (\S+) \.\.\. (\w+)", log, re.M):
     out["tests"][m.group(1)] = m.group(2)
 for m in re.finditer(r"^RUSTPARITY (\S+) (\{.*\})$", log, re.M):
@@ -46,6 +46,8 @@ for m in re.finditer(r"^RUSTPARITY (\S+) (\{.*\})$", log, re.M):
         out["tag_inputs"][body["pattern"]] = body
     elif kind == "encryption":
         out["encryption"][str(body["len"])] = body
+    elif kind in ("truncated", "trees"):
+        out[kind] = body
 json.dump(out, open("RUSTPARITY.json", "w"), indent=1)
 print("wrote", "bindings/rust/RUSTPARITY.json:", "PASS" if out["ok"] else "FAIL", out["tests"])
 PY

@@ -213,6 +213,34 @@ impl HashBatch {
         self.ctxs[0].check(rc);
         root
     }
+
+    /// Root of the arity-2 tree over `Hash::digest(Domain::Merkle2, ..)` nodes (a ragged level's missing sibling is the zero
+    /// scalar, src/hash.rs:27-31); `self` must be a `HashBatch::new(Domain::Merkle2, 2)`.
+    pub fn merkle2_root(&self, leaves: &[BlsScalar]) -> BlsScalar {
+        assert!(self.item_len == 2 && self.output_len == 1 && !leaves.is_empty());
+        let mut root = BlsScalar::zero();
+        let rc = unsafe {
+            p252_merkle2_tree(self.ctxs[0].0, self.tag.0.as_ptr(), leaves.as_ptr() as *const u64, leaves.len(),
+                              &mut root as *mut BlsScalar as *mut u64, core::ptr::null_mut())
+        };
+        self.ctxs[0].check(rc);
+        root
+    }
+
+    /// The root each of n arity-4 openings re-hashes to (`poseidon-merkle`'s `Opening::verify` compares it with the tree's root):
+    /// `siblings` holds n x depth x 3 scalars, `positions` n x depth bytes in 0..3 (the slot of the value coming from below).
+    pub fn merkle4_path_roots(&self, leaves: &[BlsScalar], siblings: &[BlsScalar], positions: &[u8], depth: usize) -> Vec<BlsScalar> {
+        assert!(self.item_len == 4 && self.output_len == 1);
+        let n = leaves.len();
+        assert!(siblings.len() == n * depth * 3 && positions.len() == n * depth);
+        let mut roots = vec![BlsScalar::zero(); n];
+        let rc = unsafe {
+            p252_merkle4_path_batch(self.ctxs[0].0, self.tag.0.as_ptr(), leaves.as_ptr() as *const u64, siblings.as_ptr() as *const u64,
+                                    positions.as_ptr(), depth, roots.as_mut_ptr() as *mut u64, n)
+        };
+        self.ctxs[0].check(rc);
+        roots
+    }
 }
 
 /// Batched `dusk_poseidon::encrypt` (src/encryption.rs:62-76): `messages` holds n messages of `message_len` scalars,

@@ -31,6 +31,90 @@ fn gpu_matches_reference_hash() {
     }
 }
 
+/// `Hash::digest_truncated` (src/hash.rs:164-183, 203-210): the library's fused output stage returns the raw limbs the reference
+/// hands to `JubJubScalar::from_raw` — so `from_raw(limbs)` must equal the reference's scalar.  Pins the `&` of the truncation
+/// (`BitAnd` of un-vendored dusk-bls12_381, VERDICT r5 "what's missing" 4).  Shapes: the truncated gadget tests' 3 / 5 / 15 inputs
+/// (tests/hash.rs:188-203), the Merkle domains, a multi-output pattern; a batch beyond the lane-group kernels.
+#[test]
+fn gpu_matches_reference_truncated() {
+    use dusk_jubjub::JubJubScalar;
+    let mut rng = StdRng::seed_from_u64(0x7250);
+    let mut all_equal = true;
+    for (domain, n_in, n_out, items) in [
+        (Domain::Other, 3, 1, 500), (Domain::Other, 5, 1, 500), (Domain::Other, 15, 1, 500), (Domain::Merkle4, 4, 1, 500),
+        (Domain::Merkle2, 2, 1, 500), (Domain::Other, 4, 7, 300), (Domain::Merkle4, 4, 1, 20_000),
+    ] {
+        let hb = HashBatch::with_output_len(domain, n_in, n_out).unwrap();
+        let input: Vec<BlsScalar> = (0..n_in * items).map(|_| BlsScalar::random(&mut rng)).collect();
+        let got = hb.digest_truncated_raw(&input);
+        for i in 0..items {
+            let mut h = Hash::new(domain);
+            h.output_len(n_out);
+            h.update(&input[i * n_in..(i + 1) * n_in]);
+            let want: Vec<JubJubScalar> = h.finalize_truncated();
+            for (k, w) in want.iter().enumerate() {
+                let g = JubJubScalar::from_raw(got[i * n_out + k]);
+                all_equal &= g == *w;
+                assert_eq!(g, *w, "{domain:?} {n_in}->{n_out} item {i} output {k}");
+                assert_eq!(got[i * n_out + k][3] >> 58, 0, "below 2^250");
+            }
+        }
+    }
+    println!("RUSTPARITY truncated {{\"rule\": \"canonical value & (2^250 - 1)\", \"matches\": {all_equal}}}");
+}
+
+/// Trees are loops of `Hash::digest` in the reference's world (the crate's own builder was removed in 0.29.0, CHANGELOG.md:164-168;
+/// downstream: poseidon-merkle).  A Merkle4 and a Merkle2 tree built level by level from `Hash::digest` calls against
+/// `p252_merkle4_tree` / `p252_merkle2_tree`, ragged sizes included (missing children = zero scalar, src/hash.rs:22-31), and one
+/// bulk verification: openings of the Merkle4 tree re-hashed by the library equal the reference-built root.
+#[test]
+fn gpu_trees_match_loops_of_hash_digest() {
+    fn reference_levels(domain: Domain, arity: usize, leaves: &[BlsScalar]) -> Vec<Vec<BlsScalar>> {
+        let mut levels = vec![leaves.to_vec()];
+        while levels.last().unwrap().len() > 1 {
+            let cur = levels.last().unwrap();
+            let mut next = Vec::new();
+            for group in cur.chunks(arity) {
+                let mut children = vec![BlsScalar::zero(); arity];
+                children[..group.len()].copy_from_slice(group);
+                next.push(Hash::digest(domain, &children)[0]);
+            }
+            levels.push(next);
+        }
+        levels
+    }
+    let mut rng = StdRng::seed_from_u64(0x7eee);
+    let h4 = HashBatch::new(Domain::Merkle4, 4).unwrap();
+    let h2 = HashBatch::new(Domain::Merkle2, 2).unwrap();
+    for n in [1usize, 4, 5, 64, 1000] {
+        let leaves: Vec<BlsScalar> = (0..n).map(|_| BlsScalar::random(&mut rng)).collect();
+        let l4 = reference_levels(Domain::Merkle4, 4, &leaves);
+        assert_eq!(h4.merkle4_root(&leaves), l4.last().unwrap()[0], "Merkle4 tree over {n} leaves");
+        let l2 = reference_levels(Domain::Merkle2, 2, &leaves);
+        assert_eq!(h2.merkle2_root(&leaves), l2.last().unwrap()[0], "Merkle2 tree over {n} leaves");
+        // Opening::verify in bulk: every leaf's path (three siblings per level, in order, the path's own node left out)
+        let depth = l4.len() - 1;
+        let mut sib = Vec::new();
+        let mut pos = Vec::new();
+        for leaf in 0..n {
+            let mut node = leaf;
+            for level in l4.iter().take(depth) {
+                let p = node & 3;
+                pos.push(p as u8);
+                for k in 0..4 {
+                    if k != p {
+                        sib.push(*level.get(node - p + k).unwrap_or(&BlsScalar::zero()));
+                    }
+                }
+                node >>= 2;
+            }
+        }
+        let roots = h4.merkle4_path_roots(&leaves, &sib, &pos, depth);
+        assert!(roots.iter().all(|r| *r == l4.last().unwrap()[0]), "openings of the {n}-leaf tree verify against the reference-built root");
+    }
+    println!("RUSTPARITY trees {{\"merkle4\": true, \"merkle2\": true, \"openings_verify\": true}}");
+}
+
 #[test]
 fn byte_format_matches_the_crate() {
     // to_bytes / from_bytes of the real crate against the library's conversions (round_constants.rs:56-71 pattern)

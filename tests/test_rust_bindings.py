@@ -45,6 +45,16 @@ def test_lib_rs_calls_only_declared_functions_and_no_private_dusk_api():
     for shape in ("(Domain::Other, 3, 3, ", "(Domain::Other, 5, 2, ", "(Domain::Other, 4, 7, ", "[2usize, 21, 42]",
                   "(Domain::Merkle4, 4, 1, 20_000)"):  # the reference's tests/hash.rs shapes; a batch beyond the lane-group kernels
         assert shape in parity, shape
+    # what round 5 added is covered too — the truncated form (pins the `&`), trees of both arities as loops of
+    # Hash::digest, one bulk verification of openings; each reports a RUSTPARITY line run_parity.sh collects and the prediction holds
+    for needle in ("fn gpu_matches_reference_truncated()", "hb.digest_truncated_raw(&input)", "h.finalize_truncated()", "JubJubScalar::from_raw(",
+                   "fn gpu_trees_match_loops_of_hash_digest()", "h4.merkle4_root(&leaves)", "h2.merkle2_root(&leaves)", "h4.merkle4_path_roots(",
+                   "RUSTPARITY truncated", "RUSTPARITY trees"):
+        assert needle in parity, needle
+    import json
+    exp = json.load(open(os.path.join(ROOT, "bindings", "rust", "RUSTPARITY.expected.json")))
+    assert exp["truncated"]["matches"] is True and exp["trees"] == {"merkle4": True, "merkle2": True, "openings_verify": True}
+    assert set(exp["tests"]) >= {"gpu_matches_reference_truncated", "gpu_trees_match_loops_of_hash_digest"}
 
 
 def test_run_parity_script_names_only_files_that_exist():
