@@ -51,6 +51,8 @@ import os
 import sys
 import time
 
+T_START = time.time()  # (stderr progress stamps: "N s since start")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -995,7 +997,11 @@ def main():
         sample = W.oracle_sample() if (rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_check) else None
         return W, elapsed, launch_ms, cb, ca, ok, sample
 
+    if rank == 0:
+        print("bench.py: set up (imports, process group, constants) %.1f s since start" % (time.time() - T_START), file=sys.stderr, flush=True)
     W, elapsed, launch_ms, cb, ca, self_ok, sample = measure(primary_key, args.log2n, args.steps, args.warmup)
+    if rank == 0:
+        print("bench.py: primary measured, %.1f s since start" % (time.time() - T_START), file=sys.stderr, flush=True)
     samples = [(primary_key,) + sample] if sample else []
     line = None
     if rank == 0:
@@ -1068,6 +1074,8 @@ def main():
         if args.secondary_log2n is not None:
             s_log2n = args.secondary_log2n + (4 if key in ("tree", "forest") else 0)
         W2, el2, lm2, cb2, ca2, ok2, sample2 = measure(key, s_log2n, s_steps, s_warm)
+        if rank == 0:  # (wall-clock progress on stderr: where a slow run — 8 ranks on a cold node — spends its time)
+            print("bench.py: secondary %s measured, %.1f s since start" % (key, time.time() - T_START), file=sys.stderr, flush=True)
         if sample2:
             samples.append((key,) + sample2)
         if rank == 0:

@@ -93,11 +93,27 @@ def test_tree_from_pageable_host_leaves_streams_the_first_level(gpu_ctx, oracle_
         assert np.array_equal(gpu_ctx.merkle4_tree(tag, lv), root)  # root-only variant (level 1 in scratch)
         idx = np.arange(0, n // 4, 9973)
         assert np.array_equal(levels[idx], oracle_mod.hash_batch(tag, lv.reshape(-1, 4, 4)[idx], 4, 1).reshape(-1, 4))
+    # arity 2 through the same pipeline.  (Until round 5 the full 2^20-leaf tree was rebuilt by the ORACLE: 1,048,575 permutations on one
+    # core, 47 s of the suite's 440.  Now: every level of the streamed build is the device kernels' digest of the level below — the
+    # Merkle2 digest kernel is compared with the oracle in tests/test_gpu_parity.py and again here on a strided sample of every
+    # level — and a 2^14-leaf tree, four chunks' worth of pairs at P252_HOST_CHUNK_MB's floor, equals the oracle's node for node.)
     tag2 = oracle_mod.tag(1, [2], 1)
     lv = oracle_mod.fill_random(0xabc9, 1 << 20)
     r2, l2 = gpu_ctx.merkle2_tree(tag2, lv, want_levels=True)
-    o2 = oracle_mod.merkle2_tree(tag2, lv, want_levels=True)
-    assert np.array_equal(r2, o2[0]) and np.array_equal(l2, o2[1])
+    assert np.array_equal(gpu_ctx.merkle2_tree(tag2, lv), r2)
+    below, off, cnt = lv, 0, 1 << 20
+    while cnt > 1:
+        cnt //= 2
+        level = l2[off:off + cnt]
+        assert np.array_equal(level, gpu_ctx.hash_batch(tag2, below.reshape(cnt, 2, 4), 2, 1).reshape(cnt, 4)), cnt
+        idx = np.arange(0, cnt, max(1, cnt // 97))
+        assert np.array_equal(level[idx], oracle_mod.hash_batch(tag2, np.ascontiguousarray(below.reshape(cnt, 2, 4)[idx]), 2, 1).reshape(-1, 4)), cnt
+        below, off = level, off + cnt
+    assert np.array_equal(r2, l2[-1])
+    small = oracle_mod.fill_random(0xabca, 1 << 14)
+    rs, ls = gpu_ctx.merkle2_tree(tag2, small, want_levels=True)
+    o2 = oracle_mod.merkle2_tree(tag2, small, want_levels=True)
+    assert np.array_equal(rs, o2[0]) and np.array_equal(ls, o2[1])
 
 
 def test_other_host_entry_points_stream_large_batches(gpu_ctx, oracle_mod):
