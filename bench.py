@@ -938,6 +938,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver); before the runtime loads
+    if os.environ.get("P252_BENCH_SHARE_GPU") == "1":
+        # test-only configuration (N ranks on ONE GPU): one hardware queue per rank.  With the runtime's default of 4, eight ranks plus the
+        # test runner's own context exceed the chip's hardware queue slots and the driver time-slices oversubscribed runlists at a
+        # granularity of seconds — measured on one box (profiles/r06_shared_gpu_queues.txt): the 8-rank rehearsal 3.8 s with 1 queue per
+        # rank, 95-143 s with 2-4.  One rank per GPU (the driver's run) is not affected and not touched.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     keep_stdout_for_the_line()
     import torch
     rank = int(os.environ.get("RANK", "0"))
