@@ -62,6 +62,12 @@ if "--long" in sys.argv:
         it += 1
         seed = int(rng.integers(1, 1 << 30))
         kind = it % 15
+        if rng.integers(0, 23) == 0:  # round 6: the grow-only scratch given back at random points between calls (p252_trim) — the next
+            import torch             # call of any kind must allocate what it needs again and still equal the oracle
+            torch.cuda.synchronize()
+            ctx.trim()
+            assert ctx.scratch_residue() == 0
+            counts["trims"] = counts.get("trims", 0) + 1
         n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 8193)), int(rng.integers(8193, 20000))]))
         if kind == 0:
             n = min(n, 12000)
@@ -244,6 +250,7 @@ if "--long" in sys.argv:
             d_root = torch.zeros(4, dtype=torch.int64, device="cuda")
             comm1.merkle4_tree_sharded_device(mtag, d, leaves_n, d_root)
             torch.cuda.synchronize()
+            comm1.check()  # (round 6: no peer reported a failed build; waits for the stream itself)
             assert np.array_equal(d_root.cpu().numpy().view(np.uint64), oracle.merkle4_tree(mtag, lv)[0]), ("sharded", leaves_n, seed)
             counts["sharded-tree leaves (RCCL, one rank)"] += leaves_n
         else:
