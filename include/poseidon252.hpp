@@ -317,6 +317,15 @@ class Comm {
         detail::check(p252_merkle4_tree_sharded_device(comm_.get(), tag.data(), d_leaves, n_leaves_local, d_root, stream), ctx_.get(),
                       "merkle4_root_sharded_device");
     }
+    // waits for `stream`, then throws if a sharded build of this communicator met a failed peer since the last check (that build's
+    // root is all-ones on every healthy rank): p252_comm_check
+    void check(void* stream = nullptr) { detail::check(p252_comm_check(comm_.get(), stream), ctx_.get(), "Comm::check"); }
+    // the RCCL shared object the library resolved for this process at run time (p252_comm_backend)
+    static std::string backend() {
+        char path[4096] = {0};
+        detail::check(p252_comm_backend(path, sizeof path), nullptr, "p252_comm_backend");
+        return path;
+    }
     p252_comm* get() const { return comm_.get(); }
 
   private:

@@ -252,6 +252,7 @@ static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm
         for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) out[t]->nccl = nc[t];
     }
     if (rc == P252_OK) rc = broadcast_and_validate(out, 0);
+    if (rc == P252_OK) g_lazy_refused.clear();  // (a creation that works — the caller's own included — lifts a remembered refusal)
     if (rc != P252_OK) {
         const std::string msg = ctxs[0]->err;
         for (auto*& c : out) {

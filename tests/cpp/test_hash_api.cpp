@@ -216,9 +216,15 @@ int main() {
             Comm comm(c, Comm::unique_id(), 0, 1);
             EXPECT(comm.rank() == 0 && comm.size() == 1);
             comm.merkle4_root_sharded_device(d_leaves, n_leaves, d_root);
+            comm.check();  // ABI 8: waits for the stream; no peer reported a failed build
             BlsScalar got{};
             EXPECT(hipDeviceSynchronize() == 0 && hipMemcpy(got.data(), d_root, 32, 2) == 0);
             EXPECT(got == merkle4_root(leaves));
+            EXPECT(Comm::backend().find("rccl") != std::string::npos);  // resolved at run time: this binary links no librccl
+            c.trim();  // the grow-only scratch given back; the communicator stays usable
+            comm.merkle4_root_sharded_device(d_leaves, n_leaves, d_root);
+            comm.check();
+            EXPECT(hipMemcpy(got.data(), d_root, 32, 2) == 0 && got == merkle4_root(leaves));
         }
         {
             Context c1(0);
