@@ -19,6 +19,7 @@
 // copy the process already holds (torch's, the application's).  No RCCL -> P252_ERR_COMM from these entry points only.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -60,14 +61,16 @@ struct p252_comm {
 
 // the RCCL entry points (rccl_dyn.hpp): set by the first successful need_rccl() and never changed afterwards — every p252_comm
 // that exists was made through it, so code that holds a communicator may use R without asking again
-static const p252rccl::Api* R = nullptr;
+// (an atomic pointer: ranks driven by one thread each — one process, several GPUs — may make their first call at the same time; they all
+// store the same address, p252rccl::api() itself is serialised)
+static std::atomic<const p252rccl::Api*> R{nullptr};
 
 static int need_rccl(p252_ctx* ctx) {
-    if (R) return P252_OK;
+    if (R.load(std::memory_order_acquire)) return P252_OK;
     std::string why;
     const p252rccl::Api* a = p252rccl::api(&why);
     if (!a) return fail(ctx, P252_ERR_COMM, why);
-    R = a;
+    R.store(a, std::memory_order_release);
     return P252_OK;
 }
 
@@ -75,7 +78,7 @@ static int need_rccl(p252_ctx* ctx) {
     do {                                                                                            \
         ncclResult_t r_ = (expr);                                                                   \
         if (r_ != ncclSuccess)                                                                      \
-            return fail(ctx, P252_ERR_COMM, std::string(#expr) + ": " + R->GetErrorString(r_));    \
+            return fail(ctx, P252_ERR_COMM, std::string(#expr) + ": " + R.load()->GetErrorString(r_));    \
     } while (0)
 
 namespace {
@@ -112,7 +115,7 @@ int comm_leave(p252_comm* c, hipStream_t st) {
 void free_comm(p252_comm* c, bool abort) {
     if (!c) return;
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
-    if (c->nccl && R) (void)(abort ? R->CommAbort(c->nccl) : R->CommDestroy(c->nccl));
+    if (c->nccl && R.load()) (void)(abort ? R.load()->CommAbort(c->nccl) : R.load()->CommDestroy(c->nccl));
     if (c->d_sub) (void)hipFree(c->d_sub);
     if (c->d_roots) (void)hipFree(c->d_roots);
     if (c->d_top) (void)hipFree(c->d_top);
@@ -136,15 +139,15 @@ int broadcast_and_validate(const std::vector<p252_comm*>& comms, int root) {
     int rc = P252_OK;
     for (size_t t = 0; t < comms.size(); ++t) scratch[t] = comms[t]->d_tab_in;  // allocated with the communicator, before any collective
     {
-        ncclResult_t r = R->GroupStart();
+        ncclResult_t r = R.load()->GroupStart();
         for (size_t t = 0; t < comms.size() && r == ncclSuccess; ++t) {
             p252_ctx* ctx = comms[t]->ctx;
             (void)hipSetDevice(ctx->device);
-            r = R->Broadcast(ctx->d_tab, scratch[t], bytes, ncclUint8, root, comms[t]->nccl, nullptr);
+            r = R.load()->Broadcast(ctx->d_tab, scratch[t], bytes, ncclUint8, root, comms[t]->nccl, nullptr);
         }
-        const ncclResult_t r2 = R->GroupEnd();
+        const ncclResult_t r2 = R.load()->GroupEnd();
         if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclBroadcast of the constant table: ") + R->GetErrorString(r));
+        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclBroadcast of the constant table: ") + R.load()->GetErrorString(r));
     }
     std::vector<int32_t> got(ref.size());
     for (size_t t = 0; t < comms.size() && rc == P252_OK; ++t) {
@@ -204,7 +207,17 @@ static std::vector<p252_comm*> clique_of(p252_ctx* const* ctxs, size_t n_ctx) {
     return v;
 }
 
-static std::string g_lazy_refused;  // why the lazy communicator of the *_multi_device entry points could not be made (empty: not tried / made)
+// why the lazy communicator of the *_multi_device entry points could not be made (empty: not tried / made); read and written under g_lazy_mu
+static std::string g_lazy_refused;
+static std::mutex g_lazy_mu;
+static std::string lazy_refused() {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
+    return g_lazy_refused;
+}
+static void set_lazy_refused(const std::string& why) {
+    std::lock_guard<std::mutex> lk(g_lazy_mu);
+    g_lazy_refused = why;
+}
 
 static bool distinct_devices(p252_ctx* const* ctxs, size_t n_ctx) {
     // (test-only: tests/test_comm_mock_ranks.py links the library against a mock RCCL that accepts several ranks on one device, to
@@ -247,12 +260,12 @@ static int create_all(p252_ctx* const* ctxs, size_t n_ctx, std::vector<p252_comm
         std::vector<int> devs(n_ctx);
         for (size_t t = 0; t < n_ctx; ++t) devs[t] = ctxs[t]->device;
         std::vector<ncclComm_t> nc(n_ctx, nullptr);
-        const ncclResult_t r = R->CommInitAll(nc.data(), (int)n_ctx, devs.data());
-        if (r != ncclSuccess) rc = fail(ctxs[0], P252_ERR_COMM, std::string("ncclCommInitAll: ") + R->GetErrorString(r));
+        const ncclResult_t r = R.load()->CommInitAll(nc.data(), (int)n_ctx, devs.data());
+        if (r != ncclSuccess) rc = fail(ctxs[0], P252_ERR_COMM, std::string("ncclCommInitAll: ") + R.load()->GetErrorString(r));
         for (size_t t = 0; t < n_ctx && rc == P252_OK; ++t) out[t]->nccl = nc[t];
     }
     if (rc == P252_OK) rc = broadcast_and_validate(out, 0);
-    if (rc == P252_OK) g_lazy_refused.clear();  // (a creation that works — the caller's own included — lifts a remembered refusal)
+    if (rc == P252_OK) set_lazy_refused("");  // (a creation that works — the caller's own included — lifts a remembered refusal)
     if (rc != P252_OK) {
         const std::string msg = ctxs[0]->err;
         for (auto*& c : out) {
@@ -280,14 +293,14 @@ static int tree_clique(const std::vector<p252_comm*>& comms, const uint64_t tag[
         if (rc == P252_OK) rc = merkle_tree_device(comms[t]->ctx, 4, tag, d_leaves[t], leaves_per_ctx, comms[t]->d_sub, nullptr, hip_streams ? hip_streams[t] : nullptr);
     }
     if (rc == P252_OK) {  // (one host thread drives every rank: a failure above means NO rank has entered the collective yet)
-        ncclResult_t r = R->GroupStart();
+        ncclResult_t r = R.load()->GroupStart();
         for (size_t t = 0; t < n && r == ncclSuccess; ++t) {
             (void)hipSetDevice(comms[t]->ctx->device);
-            r = R->AllGather(comms[t]->d_sub, comms[t]->d_roots, 32, ncclUint8, comms[t]->nccl, stream_of(t));
+            r = R.load()->AllGather(comms[t]->d_sub, comms[t]->d_roots, 32, ncclUint8, comms[t]->nccl, stream_of(t));
         }
-        const ncclResult_t r2 = R->GroupEnd();
+        const ncclResult_t r2 = R.load()->GroupEnd();
         if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclAllGather of the subtree roots: ") + R->GetErrorString(r));
+        if (r != ncclSuccess) rc = fail(comms[0]->ctx, P252_ERR_COMM, std::string("ncclAllGather of the subtree roots: ") + R.load()->GetErrorString(r));
     }
     for (size_t t = 0; t < n && rc == P252_OK; ++t) {
         void* dst = (d_root_out && d_root_out[t]) ? d_root_out[t] : comms[t]->d_top;
@@ -325,8 +338,9 @@ int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t t
         std::lock_guard<std::mutex> lk(mu);
         // a lazy creation that failed once is not retried on every call (ncclCommInitAll takes 0.1-1 s to refuse): the reason
         // is kept for p252_merkle4_tree_multi_device_resident's message, the caller of this function gathers through the host
-        if (!g_lazy_refused.empty()) {
-            if (unavailable_why) *unavailable_why = g_lazy_refused;
+        const std::string refused = lazy_refused();
+        if (!refused.empty()) {
+            if (unavailable_why) *unavailable_why = refused;
             return P252_OK;
         }
         // ABI 5 accepted ANY array of contexts.  A context that already sits in a communicator over ANOTHER array (other count,
@@ -350,8 +364,9 @@ int tree_multi_device_rccl(p252_ctx* const* ctxs, size_t n_ctx, const uint64_t t
             }
         int rc = create_all(ctxs, n_ctx, comms, /*owned=*/true);
         if (rc) {  // no communicator to be had (no RCCL in the process, ncclCommInitAll refused): the host gather still exists — the caller takes it
-            g_lazy_refused = ctxs[0]->err.empty() ? std::string("communicator creation failed") : ctxs[0]->err;
-            if (unavailable_why) *unavailable_why = g_lazy_refused;
+            const std::string why = ctxs[0]->err.empty() ? std::string("communicator creation failed") : ctxs[0]->err;
+            set_lazy_refused(why);
+            if (unavailable_why) *unavailable_why = why;
             ctxs[0]->err.clear();
             return P252_OK;
         }
@@ -369,7 +384,7 @@ int p252_comm_unique_id(void* id_out, size_t len) {
     int rc = need_rccl(nullptr);
     if (rc) return rc;
     ncclUniqueId id;
-    NCCL_TRY(nullptr, R->GetUniqueId(&id));
+    NCCL_TRY(nullptr, R.load()->GetUniqueId(&id));
     std::memcpy(id_out, id.internal, P252_COMM_ID_BYTES);
     return P252_OK;
 }
@@ -393,8 +408,8 @@ int p252_comm_create_rank(p252_ctx* ctx, const void* id, size_t len, int rank, i
     if (rc == P252_OK) {
         ncclUniqueId uid;
         std::memcpy(uid.internal, id, P252_COMM_ID_BYTES);
-        const ncclResult_t r = R->CommInitRank(&c->nccl, world, uid, rank);
-        if (r != ncclSuccess) rc = fail(ctx, P252_ERR_COMM, std::string("ncclCommInitRank: ") + R->GetErrorString(r));
+        const ncclResult_t r = R.load()->CommInitRank(&c->nccl, world, uid, rank);
+        if (r != ncclSuccess) rc = fail(ctx, P252_ERR_COMM, std::string("ncclCommInitRank: ") + R.load()->GetErrorString(r));
     }
     if (rc == P252_OK) {
         ctx->comm = c;
@@ -434,7 +449,7 @@ int p252_comm_backend(char* path_out, size_t len) {
     const int rc = need_rccl(nullptr);
     if (rc) return rc;
     if (path_out && len) {
-        std::strncpy(path_out, R->origin.c_str(), len - 1);
+        std::strncpy(path_out, R.load()->origin.c_str(), len - 1);
         path_out[len - 1] = 0;
     }
     return P252_OK;
@@ -462,13 +477,13 @@ int p252_merkle4_tree_sharded_device(p252_comm* comm, const uint64_t tag[4], con
         // p252_comm_check / p252_sync report P252_ERR_COMM naming this rank (they used to return a garbage root as P252_OK).
         const std::string msg = ctx->err;
         (void)hipMemsetAsync(comm->d_sub, 0xff, 32, st);
-        (void)R->AllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st);
+        (void)R.load()->AllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st);
         (void)comm_leave(comm, st);
         ctx->err = msg;
         return rc;
     }
     // ... the path's only exchange step, on the same stream: world x 32 bytes to every rank ...
-    NCCL_TRY(ctx, R->AllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st));
+    NCCL_TRY(ctx, R.load()->AllGather(comm->d_sub, comm->d_roots, 32, ncclUint8, comm->nccl, st));
     // ... and the top levels, on every rank (a single rank's "tree over one root" is a copy)
     rc = merkle_tree_device(ctx, 4, tag, comm->d_roots, (size_t)comm->world, d_root, nullptr, hip_stream);
     if (rc == P252_OK && p252::launch_poison_if_peer_failed(comm->d_roots, (unsigned)comm->world, d_root, comm->d_fail, st) != hipSuccess)
