@@ -73,7 +73,7 @@ extern "C" {
  *   6  + the RCCL communicator (p252_comm_*), p252_merkle4_tree_sharded_device, p252_merkle4_tree_multi_device_resident,
  *      p252_merkle4_forest[_device], p252_merkle2_forest_device, p252_merkle{4,2}_openings_device, p252_merkle{4,2}_depth,
  *      p252_merkle2_path_batch_device, P252_ERR_COMM; p252_merkle4_tree_multi_device exchanges the subtree roots with one
- *      ncclAllGather whenever its contexts sit on distinct devices (the library links librccl from this version on)
+ *      ncclAllGather whenever its contexts sit on distinct devices (versions 6 and 7 linked librccl; version 8 resolves it at run time)
  *   7  + p252_hash_batch_truncated[_device] (finalize_truncated fused into the digest kernels' output stage: one launch),
  *      p252_wipe, p252_scratch_residue, p252_merkle{4,2}_verify_batch_device; the host-buffer p252_{encrypt,decrypt}_batch and p252_destroy clear the library-owned
  *      copies of what they were handed; root-only tree / forest builds on DIFFERENT streams of one context no longer share
