@@ -117,3 +117,38 @@ def test_rustparity_expected_is_the_librarys_prediction():
         lines = r.stdout.decode().splitlines()
         assert r.returncode == 1 and len(lines) == 4, lines
         assert any("tag_inputs.merkle4_4_1.bytes" in l for l in lines) and any("encryption.21.stream" in l for l in lines) and any("missing from the run" in l for l in lines)
+
+
+def test_rust_sources_are_lexically_balanced():
+    """No Rust toolchain here: the least that can be checked mechanically is that every source of the shim and of refgen has balanced
+    (), [], {} outside comments, strings and char literals — a truncated edit or a stray brace is caught before someone with cargo is"""
+    def balanced(path):
+        s = open(path).read()
+        out, i, n = [], 0, len(s)
+        while i < n:
+            if s.startswith("//", i):
+                j = s.find("\n", i)
+                i = n if j < 0 else j
+            elif s.startswith("/*", i):
+                i = s.find("*/", i + 2) + 2
+            elif s[i] == '"':
+                j = i + 1
+                while j < n and s[j] != '"':
+                    j += 2 if s[j] == "\\" else 1
+                i = j + 1
+            elif s[i] == "'" and re.match(r"'(\\.|[^\\'])'", s[i:]):
+                i += re.match(r"'(\\.|[^\\'])'", s[i:]).end()
+            else:
+                out.append(s[i])
+                i += 1
+        stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+        for ch in out:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in ")]}":
+                if not stack or stack.pop() != pairs[ch]:
+                    return False
+        return not stack
+    rust = os.path.join(ROOT, "bindings", "rust")
+    for rel in ("src/lib.rs", "src/sys.rs", "tests/parity.rs", "build.rs", "refgen/src/main.rs"):
+        assert balanced(os.path.join(rust, rel)), rel
